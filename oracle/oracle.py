@@ -1,0 +1,160 @@
+"""ctypes binding of the TEST ORACLE (oracle/libita_oracle.so).
+
+Test infrastructure only: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libita_oracle.so")
+    src = os.path.join(_HERE, "ita_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libita_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libita_oracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+        _LIB.ita_oracle_expf.restype = C.c_float
+        _LIB.ita_oracle_expf.argtypes = [C.c_float]
+        _LIB.ita_oracle_softmax_inverse.restype = C.c_int32
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def tokenizer(img, cw, cb, lnw, lnb):
+    img = _c(img, np.float32).reshape(-1, 60, 90)
+    B, E = img.shape[0], cw.shape[0]
+    out = np.empty((B, 128, E), np.float32)
+    lib().ita_oracle_tokenizer(_p(img), B, E, _p(_c(cw, np.float32)), _p(_c(cb, np.float32)),
+                               _p(_c(lnw, np.float32)), _p(_c(lnb, np.float32)), _p(out))
+    return out
+
+
+def quantize(x, inv_scale):
+    x = _c(x, np.float32)
+    q = np.empty(x.shape, np.int8)
+    lib().ita_oracle_quantize(_p(x), C.c_size_t(x.size), C.c_float(inv_scale), _p(q))
+    return q
+
+
+def linear_q(x, w, bq, mult, relu=False):
+    x, w = _c(x, np.int8), _c(w, np.int8)
+    rows, K, N = x.size // x.shape[-1], x.shape[-1], w.shape[0]
+    y = np.empty(x.shape[:-1] + (N,), np.int8)
+    lib().ita_oracle_linear_q(_p(x), rows, K, N, _p(w), _p(_c(bq, np.int32)), C.c_float(mult), int(relu), _p(y))
+    return y
+
+
+def softmax(logits):
+    x = _c(logits, np.int8)
+    y = np.empty(x.shape, np.uint8)
+    lib().ita_oracle_softmax(_p(x), x.size // x.shape[-1], x.shape[-1], _p(y))
+    return y
+
+
+def mha(x, t, i=0, taps=False):
+    """t: blob-name keyed tensors (params.attention_tensors).  Returns out_f [, dict of taps]."""
+    x = _c(x, np.float32)
+    B, S, E = x.shape
+    P = t[f"attn{i}.wq"].shape[0]
+    out = np.empty_like(x)
+    tp = {}
+    if taps:
+        tp = dict(x_q=np.empty((B, S, E), np.int8), Q=np.empty((B, S, P), np.int8), K=np.empty((B, S, P), np.int8),
+                  V=np.empty((B, S, P), np.int8), logits=np.empty((B, S, S), np.int8),
+                  probs=np.empty((B, S, S), np.uint8), ctx=np.empty((B, S, P), np.int8),
+                  out_q=np.empty((B, S, E), np.int8))
+    order = ("x_q", "Q", "K", "V", "logits", "probs", "ctx", "out_q")
+    lib().ita_oracle_mha(_p(x), B, S, E, P, _p(t[f"attn{i}.wq"]), _p(t[f"attn{i}.bq"]), _p(t[f"attn{i}.wk"]),
+                         _p(t[f"attn{i}.bk"]), _p(t[f"attn{i}.wv"]), _p(t[f"attn{i}.bv"]), _p(t[f"attn{i}.wo"]),
+                         _p(t[f"attn{i}.bo"]), _p(t[f"attn{i}.scal"]), _p(out), *[_p(tp.get(k)) for k in order])
+    return (out, tp) if taps else out
+
+
+def ffn(x, t, i=0, taps=False):
+    x = _c(x, np.float32)
+    B, S, E = x.shape
+    F = t[f"ffn{i}.w1"].shape[0]
+    out = np.empty_like(x)
+    tp = {}
+    if taps:
+        tp = dict(x_q=np.empty((B, S, E), np.int8), h=np.empty((B, S, F), np.int8), out_q=np.empty((B, S, E), np.int8))
+    lib().ita_oracle_ffn(_p(x), B, S, E, F, _p(t[f"ffn{i}.w1"]), _p(t[f"ffn{i}.b1"]), _p(t[f"ffn{i}.w2"]),
+                         _p(t[f"ffn{i}.b2"]), _p(t[f"ffn{i}.scal"]), _p(out),
+                         *[_p(tp.get(k)) for k in ("x_q", "h", "out_q")])
+    return (out, tp) if taps else out
+
+
+def add_ln(x, y, w, b):
+    x, y = _c(x, np.float32), _c(y, np.float32)
+    E = x.shape[-1]
+    out = np.empty_like(x)
+    lib().ita_oracle_add_ln(_p(x), _p(y), x.size // E, E, _p(_c(w, np.float32)), _p(_c(b, np.float32)), _p(out))
+    return out
+
+
+def tail(x2, cw, cb, want_fused=False):
+    x2 = _c(x2, np.float32)
+    B, _, E = x2.shape
+    feat = np.empty((B, 9 * 16 * 32), np.float32)
+    fused = np.empty((B, E // 4 + E, 16, 32), np.float32) if want_fused else None
+    lib().ita_oracle_tail(_p(x2), B, E, _p(_c(cw, np.float32)), _p(_c(cb, np.float32)), _p(feat), _p(fused))
+    return (feat, fused) if want_fused else feat
+
+
+def linear_f32(x, w, b):
+    x, w = _c(x, np.float32), _c(w, np.float32)
+    rows, K, N = x.size // x.shape[-1], x.shape[-1], w.shape[0]
+    y = np.empty(x.shape[:-1] + (N,), np.float32)
+    lib().ita_oracle_linear_f32(_p(x), rows, K, N, _p(w), _p(_c(b, np.float32)), _p(y))
+    return y
+
+
+def forward(blob: bytes, image, desvel, quat, h_in=None, c_in=None, taps=False):
+    """module.main_graph semantics with leading batch (QAT/model.py:93-132)."""
+    image = np.ascontiguousarray(image)
+    is_u8 = image.dtype == np.uint8
+    if not is_u8:
+        image = image.astype(np.float32)
+    B = image.reshape(-1, 60, 90).shape[0]
+    E = np.frombuffer(blob[12:16], np.int32)[0]
+    desvel, quat = _c(desvel, np.float32).reshape(B), _c(quat, np.float32).reshape(B, 4)
+    h_in = np.zeros((3, B, 128), np.float32) if h_in is None else _c(h_in, np.float32)
+    c_in = np.zeros((3, B, 128), np.float32) if c_in is None else _c(c_in, np.float32)
+    vel = np.empty((B, 3), np.float32)
+    h_out, c_out = np.empty((3, B, 128), np.float32), np.empty((3, B, 128), np.float32)
+    tp = {}
+    if taps:
+        tp = dict(tokens=np.empty((B, 128, E), np.float32), x1=np.empty((B, 128, E), np.float32),
+                  x2=np.empty((B, 128, E), np.float32), feat=np.empty((B, 4608), np.float32),
+                  dec=np.empty((B, 512), np.float32))
+    buf = C.create_string_buffer(blob, len(blob))
+    rc = lib().ita_oracle_forward(buf, C.c_size_t(len(blob)), _p(image), int(is_u8), _p(desvel), _p(quat), _p(h_in),
+                                  _p(c_in), B, _p(vel), _p(h_out), _p(c_out),
+                                  *[_p(tp.get(k)) for k in ("tokens", "x1", "x2", "feat", "dec")])
+    if rc != 0:
+        raise RuntimeError(f"ita_oracle_forward rc={rc}")
+    return (vel, h_out, c_out, tp) if taps else (vel, h_out, c_out)

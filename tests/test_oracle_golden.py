@@ -1,0 +1,175 @@
+"""Pins the CPU oracle (oracle/ita_oracle.c) against golden vectors captured from the
+reference's own PyTorch int8 modules (tools/gen_golden.py, run in the build container).
+
+Integer stages: bit-exact, each stage fed with the fixture's own input for that stage.
+matmul1 (QK^T): the reference goes through a float32 sgemm (torch.ops.quantized.matmul fallback:
+dequantize -> matmul -> quantize), so elements whose exact product is within 2e-4 of a rounding
+tie may differ by one LSB; the test proves every mismatch is such a near-tie and that there
+are at most 3 per fixture.
+Float stages: <= 2e-5 absolute (PyTorch's conv / LayerNorm / LSTM summation order is not ours).
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_files
+from drone_oa_iree_vit_accelerator_amd import params, synth
+
+FIX_ALL = golden_files("*_seed*.npz")
+FIX_VIT = golden_files("vitlstm_*.npz")
+
+
+def _ids(paths):
+    return [p.split("/")[-1][:-4] for p in paths]
+
+
+def test_fixtures_present():
+    assert len(FIX_ALL) >= 6 and len(FIX_VIT) >= 3
+
+
+def test_softmax_rows(oracle):
+    d = params.load_fixture(golden_files("softmax_rows.npz")[0])
+    assert float(d["out_scale"]) == 1.0 / 255.0
+    y = oracle.softmax(d["x"])
+    np.testing.assert_array_equal(y, d["y"])
+
+
+def test_softmax_inverse_exhaustive(oracle):
+    """floor(fp32(255*2^16 / sum)) for every reachable denominator equals the reference's tensor
+    expression AND exact integer floor division (so a kernel may use either)."""
+    inv_ref = params.load_fixture(golden_files("softmax_inverse.npz")[0])["inv"]
+    sums = np.arange(1, 32769, dtype=np.int64)
+    ours = np.array([oracle.lib().ita_oracle_softmax_inverse(int(s)) for s in sums])
+    np.testing.assert_array_equal(ours, inv_ref)
+    np.testing.assert_array_equal(ours[255:], (16711680 // sums)[255:])   # reachable sums are >= 256
+
+
+def test_softmax_all_diffs(oracle):
+    """every diff 0..255 against the closed form y = ((256 >> d) * inv) >> 16"""
+    rows = []
+    for d in range(256):
+        r = np.full(128, -128 + 0, np.int16)
+        r[:] = 127 - d
+        r[0] = 127
+        rows.append(np.clip(r, -128, 127).astype(np.int8))
+    x = np.stack(rows)
+    y = oracle.softmax(x)
+    for d in range(256):
+        xi = x[d].astype(np.int64)
+        n = np.where(xi.max() - xi > 31, 0, 256 >> np.minimum(xi.max() - xi, 31))
+        inv = 16711680 // max(int(n.sum()), 1)
+        np.testing.assert_array_equal(y[d], (n * inv) >> 16)
+
+
+@pytest.mark.parametrize("path", FIX_ALL, ids=_ids(FIX_ALL))
+def test_attention_stages(oracle, path):
+    d = params.load_fixture(path)
+    t = params.attention_tensors(d, "attn0.", 0)
+    sc = t["attn0.scal"]
+    xq = oracle.quantize(d["s0.attn0.x_q.in"], sc[0])
+    np.testing.assert_array_equal(xq, d["s0.attn0.x_q"])
+    for nm, key, m in (("Q", "q", 1), ("K", "k", 2), ("V", "v", 3)):
+        y = oracle.linear_q(d["s0.attn0.x_q"], t[f"attn0.w{key}"], t[f"attn0.b{key}"], sc[m])
+        np.testing.assert_array_equal(y, d[f"s0.attn0.{nm}"])
+    # matmul1 with near-tie analysis
+    Q, K = d["s0.attn0.Q"].astype(np.int64), d["s0.attn0.K"].astype(np.int64)
+    acc = Q @ K.transpose(0, 2, 1)
+    ours = np.clip(np.rint(acc.astype(np.float32) * sc[4]), -128, 127).astype(np.int8)
+    ref = d["s0.attn0.probs.in"][:, 0]
+    bad = np.argwhere(ours != ref)
+    assert len(bad) <= 3
+    for b, i, j in bad:
+        exact = float(acc[b, i, j]) * float(sc[4])
+        assert abs(abs(exact - np.floor(exact)) - 0.5) < 2e-4 and abs(int(ours[b, i, j]) - int(ref[b, i, j])) == 1
+    probs = oracle.softmax(ref)
+    np.testing.assert_array_equal(probs, d["s0.attn0.probs"][:, 0])
+    # matmul2 + out_proj + dequant from the fixture's probs / V
+    A, V = d["s0.attn0.probs"][:, 0].astype(np.int64), d["s0.attn0.V"].astype(np.int64)
+    ctx = np.clip(np.rint((A @ V).astype(np.float32) * sc[5]), -128, 127).astype(np.int8)
+    np.testing.assert_array_equal(ctx, d["s0.attn0.out_q.in"])
+    o = oracle.linear_q(d["s0.attn0.out_q.in"], t["attn0.wo"], t["attn0.bo"], sc[6])
+    np.testing.assert_array_equal(o, d["s0.attn0.out_q"])
+    np.testing.assert_array_equal(o.astype(np.float32) * sc[7], d["s0.attn0.out_f"])
+
+
+@pytest.mark.parametrize("path", FIX_ALL, ids=_ids(FIX_ALL))
+def test_attention_block_end_to_end(oracle, path):
+    """whole ita_oracle_mha from the float block input; only rows touched by a near-tie logit
+    may differ from the reference."""
+    d = params.load_fixture(path)
+    t = params.attention_tensors(d, "attn0.", 0)
+    out, tp = oracle.mha(d["s0.attn0.x_q.in"], t, taps=True)
+    np.testing.assert_array_equal(tp["x_q"], d["s0.attn0.x_q"])
+    np.testing.assert_array_equal(tp["Q"], d["s0.attn0.Q"])
+    np.testing.assert_array_equal(tp["K"], d["s0.attn0.K"])
+    np.testing.assert_array_equal(tp["V"], d["s0.attn0.V"])
+    ref_l = d["s0.attn0.probs.in"][:, 0]
+    bad_rows = {(b, i) for b, i, _ in np.argwhere(tp["logits"] != ref_l)}
+    assert len(bad_rows) <= 3
+    mask = np.ones(ref_l.shape[:2], bool)
+    for b, i in bad_rows:
+        mask[b, i] = False
+    np.testing.assert_array_equal(tp["probs"][mask], d["s0.attn0.probs"][:, 0][mask])
+    np.testing.assert_array_equal(tp["ctx"][mask], d["s0.attn0.out_q.in"][mask])
+    np.testing.assert_array_equal(tp["out_q"][mask], d["s0.attn0.out_q"][mask])
+    np.testing.assert_array_equal(out[mask], d["s0.attn0.out_f"][mask])
+    assert np.abs(tp["out_q"].astype(int) - d["s0.attn0.out_q"].astype(int)).max() <= 2
+
+
+@pytest.mark.parametrize("path", FIX_ALL, ids=_ids(FIX_ALL))
+def test_ffn_block(oracle, path):
+    d = params.load_fixture(path)
+    t = params.ffn_tensors(d, "ffn0.", 0)
+    out, tp = oracle.ffn(d["s0.ffn0.x_q.in"], t, taps=True)
+    np.testing.assert_array_equal(tp["x_q"], d["s0.ffn0.x_q"])
+    np.testing.assert_array_equal(tp["h"], d["s0.ffn0.h1_relu"])
+    np.testing.assert_array_equal(np.maximum(d["s0.ffn0.h1"], 0), d["s0.ffn0.h1_relu"])
+    np.testing.assert_array_equal(tp["out_q"], d["s0.ffn0.out_q"])
+    np.testing.assert_array_equal(out, d["s0.ffn0.out_f"])
+
+
+@pytest.mark.parametrize("path", FIX_VIT, ids=_ids(FIX_VIT))
+def test_float_stages(oracle, path):
+    d = params.load_fixture(path)
+    seed = int(d["meta.seed"])
+    fp = synth.float_params(seed, E=64)
+    assert synth.digest(fp) == str(d["meta.params_sha256"]), "synthetic parameter generator drifted"
+    img = d["in0.img_u8"].astype(np.float32) / np.float32(255.0)
+    tok = oracle.tokenizer(img, fp["tokenizer.conv.weight"].reshape(64, 49), fp["tokenizer.conv.bias"],
+                           fp["tokenizer.norm.weight"], fp["tokenizer.norm.bias"])
+    np.testing.assert_allclose(tok, d["s0.tok.out"], atol=2e-5, rtol=0)
+    x1 = oracle.add_ln(d["s0.attn0.x_q.in"], d["s0.attn0.out_f"], fp["norms1.0.weight"], fp["norms1.0.bias"])
+    np.testing.assert_allclose(x1, d["s0.x1"], atol=2e-5, rtol=0)
+    x2 = oracle.add_ln(d["s0.ffn0.x_q.in"], d["s0.ffn0.out_f"], fp["norms2.0.weight"], fp["norms2.0.bias"])
+    np.testing.assert_allclose(x2, d["s0.x2"], atol=2e-5, rtol=0)
+    feat, fused = oracle.tail(d["s0.x2"], fp["down_sample.weight"], fp["down_sample.bias"], want_fused=True)
+    np.testing.assert_array_equal(fused[:, :16], d["s0.tail.shuffled"])
+    np.testing.assert_allclose(fused[:, 16:], d["s0.tail.upsampled"], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(feat.reshape(-1, 9, 16, 32), d["s0.tail.conv"], atol=2e-5, rtol=0)
+    dec = oracle.linear_f32(d["s0.tail.conv"].reshape(-1, 4608), fp["decoder.weight"], fp["decoder.bias"])
+    np.testing.assert_allclose(dec, d["s0.dec"], atol=2e-5, rtol=0)
+
+
+@pytest.mark.parametrize("path", FIX_VIT, ids=_ids(FIX_VIT))
+def test_full_forward_two_steps(oracle, path):
+    """module.main_graph twice, carrying (h, c) like the reference host.  The int8 blocks sit
+    behind float LayerNorms, so a 1e-7 float difference can flip an int8 code; the end-to-end
+    bound is therefore looser than the per-stage ones (observed: < 2e-4 on velocity)."""
+    d = params.load_fixture(path)
+    fp = synth.float_params(int(d["meta.seed"]), E=64)
+    blob = params.blob_from_record(d, fp, E=64)
+    vel0, h0, c0, tp = oracle.forward(blob, d["in0.img_u8"], d["in0.desvel"], d["in0.quat"], taps=True)
+    np.testing.assert_allclose(tp["tokens"], d["s0.tok.out"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(tp["x1"], d["s0.x1"], atol=5e-2, rtol=0)
+    assert np.mean(np.abs(tp["x1"] - d["s0.x1"]) > 1e-4) < 2e-3      # isolated int8 flips only
+    np.testing.assert_allclose(tp["dec"], d["s0.dec"], atol=2e-3, rtol=0)
+    np.testing.assert_allclose(vel0, d["s0.vel"], atol=5e-4, rtol=0)
+    np.testing.assert_allclose(h0, d["s0.h"], atol=5e-4, rtol=0)
+    np.testing.assert_allclose(c0, d["s0.c"], atol=5e-4, rtol=0)
+    vel1, h1, c1 = oracle.forward(blob, d["in1.img_u8"], d["in1.desvel"], d["in1.quat"], d["s0.h"], d["s0.c"])
+    np.testing.assert_allclose(vel1, d["s1.vel"], atol=5e-4, rtol=0)
+    np.testing.assert_allclose(h1, d["s1.h"], atol=5e-4, rtol=0)
+    np.testing.assert_allclose(c1, d["s1.c"], atol=5e-4, rtol=0)
+    # float-image entry point gives the same result as the u8 wire entry point
+    img_f = d["in0.img_u8"].astype(np.float32) / np.float32(255.0)
+    vel0f, _, _ = oracle.forward(blob, img_f, d["in0.desvel"], d["in0.quat"])
+    np.testing.assert_array_equal(vel0f, vel0)
