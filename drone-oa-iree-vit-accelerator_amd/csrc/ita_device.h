@@ -1,0 +1,118 @@
+// ita_device.h -- device-side helpers shared by the gfx950 kernels.
+//
+// Conventions used by every int8 kernel in this directory
+// -------------------------------------------------------
+// * All int8 GEMMs are "NT": C[m][n] = sum_k A[m][k] * Bt[n][k], both operands k-contiguous,
+//   so one MFMA fragment is 16 contiguous bytes of one row.  The integer sum does not care
+//   which k a fragment byte really is, only that A and Bt use the same slot -> k mapping,
+//   which lets the attention kernel feed softmax outputs straight from registers (see
+//   ita_int8_kernels.h).
+// * int8 operand matrices that live in LDS are stored "chunk-major": [k/16][row][16 bytes].
+//   A wave's ds_read_b128 of one fragment column then touches 16 consecutive 16-byte slots per
+//   lane group -> conflict-free for both the 32x32x32 and the 16x16x64 MFMA access patterns,
+//   with no padding.
+// * v_mfma_i32_32x32x32_i8 : A lane l -> row l&31, k-slot group l>>5 (16 bytes);
+//                            C lane l -> col l&31, row (i&3) + 8*(i>>2) + 4*(l>>5), i = 0..15
+//   v_mfma_i32_16x16x64_i8 : A lane l -> row l&15, k-slot group l>>4 (16 bytes);
+//                            C lane l -> col l&15, row 4*(l>>4) + i, i = 0..3
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define ITA_MAGIC_F 12582912.0f   /* 1.5 * 2^23: adding it rounds to nearest-even integer */
+#define ITA_MAGIC_I 0x4B400000
+
+// byte offset of (row, k-byte) in a chunk-major int8 matrix with ROWS rows
+__device__ __forceinline__ int cm_off(int row, int kb, int rows) {
+  return ((((kb >> 4) * rows) + row) << 4) | (kb & 15);
+}
+
+// nnq requantisation: clamp(rne(float(acc) * mult), lo, 127).  The clamp is applied before the
+// rounding (same result, the bounds are integers); the rounding is the fp32 add of 1.5*2^23,
+// whose mantissa then holds the two's-complement integer: returns those bits.
+__device__ __forceinline__ unsigned rq_bits(int acc, float mult, float lo = -128.0f) {
+  float f = (float)acc * mult;
+  f = __builtin_amdgcn_fmed3f(f, lo, 127.0f);
+  f = f + ITA_MAGIC_F;
+  return __float_as_uint(f);
+}
+__device__ __forceinline__ unsigned q_bits(float x, float inv_scale) {   // torch.quantize_per_tensor
+  float f = x * inv_scale;
+  f = __builtin_amdgcn_fmed3f(f, -128.0f, 127.0f);
+  f = f + ITA_MAGIC_F;
+  return __float_as_uint(f);
+}
+__device__ __forceinline__ int bits_to_int(unsigned b) { return (int)b - ITA_MAGIC_I; }
+__device__ __forceinline__ unsigned pack4(unsigned b0, unsigned b1, unsigned b2, unsigned b3) {
+  return (b0 & 0xffu) | ((b1 & 0xffu) << 8) | ((b2 & 0xffu) << 16) | (b3 << 24);
+}
+
+// exp with a fixed arithmetic, identical to oracle/ita_oracle.c:ita_oracle_expf
+__device__ __forceinline__ float ita_expf(float x) {
+  x = fminf(fmaxf(x, -87.0f), 88.0f);
+  float n = rintf(x * 1.44269504088896341f);
+  float r = fmaf(n, -0.693359375f, x);
+  r = fmaf(n, 2.12194440e-4f, r);
+  float p = 1.9875691500E-4f;
+  p = fmaf(p, r, 1.3981999507E-3f);
+  p = fmaf(p, r, 8.3334519073E-3f);
+  p = fmaf(p, r, 4.1665795894E-2f);
+  p = fmaf(p, r, 1.6666665459E-1f);
+  p = fmaf(p, r, 5.0000001201E-1f);
+  float r2 = r * r;
+  p = fmaf(p, r2, r) + 1.0f;
+  float s = __uint_as_float((unsigned)((int)n + 127) << 23);
+  return p * s;
+}
+__device__ __forceinline__ float ita_sigmoid(float x) { return 1.0f / (1.0f + ita_expf(-x)); }
+__device__ __forceinline__ float ita_tanh(float x) { return 1.0f - 2.0f / (ita_expf(2.0f * x) + 1.0f); }
+
+// LayerNorm over E channels spread over NT adjacent lanes (NT = 2 or 4), each holding EC = E/NT
+// consecutive channels, in the oracle's summation order: 4 blocks of E/4 consecutive channels
+// summed sequentially, combined (p0+p1)+(p2+p3).   r[] is overwritten with the result.
+template <int E, int NT>
+__device__ __forceinline__ void layernorm_lanes(float (&r)[E / NT], const float* __restrict__ w,
+                                                const float* __restrict__ b, int c0) {
+  constexpr int EC = E / NT, Q = E / 4;
+  const float inv_e = 1.0f / (float)E;
+  float tot;
+  if constexpr (NT == 4) {
+    float p = 0.0f;
+#pragma unroll
+    for (int i = 0; i < EC; ++i) p = p + r[i];
+    float s1 = p + __shfl_xor(p, 1);
+    tot = s1 + __shfl_xor(s1, 2);
+  } else {
+    float pa = 0.0f, pb = 0.0f;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) pa = pa + r[i];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) pb = pb + r[Q + i];
+    float s1 = pa + pb;
+    tot = s1 + __shfl_xor(s1, 1);
+  }
+  const float mean = tot * inv_e;
+  if constexpr (NT == 4) {
+    float p = 0.0f;
+#pragma unroll
+    for (int i = 0; i < EC; ++i) { float d = r[i] - mean; p = fmaf(d, d, p); }
+    float s1 = p + __shfl_xor(p, 1);
+    tot = s1 + __shfl_xor(s1, 2);
+  } else {
+    float pa = 0.0f, pb = 0.0f;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) { float d = r[i] - mean; pa = fmaf(d, d, pa); }
+#pragma unroll
+    for (int i = 0; i < Q; ++i) { float d = r[Q + i] - mean; pb = fmaf(d, d, pb); }
+    float s1 = pa + pb;
+    tot = s1 + __shfl_xor(s1, 1);
+  }
+  const float var = tot * inv_e;
+  const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < EC; ++i) r[i] = fmaf((r[i] - mean) * rstd, w[c0 + i], b[c0 + i]);
+}

@@ -1,0 +1,306 @@
+// ita_f32_kernels.h -- the float32 layers around the int8 blocks.
+//
+// Every kernel here uses the oracle's operation order (oracle/ita_oracle.c): one ascending-k
+// fmaf chain per output started from the bias, LayerNorm sums in four blocks.  The translation
+// unit is compiled with -ffp-contract=off, so the only fused multiply-adds are the explicit
+// fmaf() calls and the f32 MFMA, which is itself a k-ordered fmaf chain on gfx950.
+//
+//   ita_tokenizer_kernel   OverlapPatchMerging: conv7x7 s2 p3 + bilinear(30x45->8x16) + LayerNorm
+//                          (reference models/ITA/QAT/layers.py:39-45)
+//   ita_tail_kernel        PixelShuffle(2) || Upsample(16,32,align_corners) -> cat -> conv3x3 -> 9x16x32
+//                          (reference models/ITA_single_layer_upsample_shuffle/QAT/model.py:116-121)
+//   ita_gemm_f32_kernel    y = x W^T + b on v_mfma_f32_16x16x4_f32 (decoder Linear 4608->512,
+//                          LSTM gate pre-activations)                      (QAT/model.py:124,128)
+//   ita_lstm_prep_kernel / ita_lstm_point_kernel / ita_fc_kernel   concat, LSTM cell, fc 128->3
+//                          (QAT/model.py:126-130)
+#pragma once
+#include "ita_device.h"
+
+// ------------------------------------------------------------------ tokenizer
+struct ItaTokArgs {
+  const void* img;    // (B,60,90) f32, or u8 wire frames
+  const float* cw;    // [E][49]
+  const float* cb;    // [E]
+  const float *ln_w, *ln_b;
+  float* tokens;      // (B,128,E)
+  int B;
+};
+
+__device__ __forceinline__ void bilinear_src_dev(int dst, float scale, int in, int& i0, int& ip, float& l1) {
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  if (src < 0.0f) src = 0.0f;
+  int i = (int)src;
+  if (i > in - 1) i = in - 1;
+  i0 = i;
+  ip = (i < in - 1) ? 1 : 0;
+  l1 = src - (float)i;
+}
+
+template <int E, bool U8>
+__global__ __launch_bounds__(256) void ita_tokenizer_kernel(const ItaTokArgs a) {
+  constexpr int PH = 66, PW = 96;        // 60x90 frame with a 3-pixel zero border (+3 right for the tap shift)
+  constexpr int EC = E / 2;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float* img = (float*)lds;              // [PH][PW]
+  float* pb = img + PH * PW;             // [128][49] blended patches
+  float* wt = pb + 128 * 49;             // [49][E]   conv weights, k-major
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 49 * E; i += 256) {
+    const int k = i / E, c = i - k * E;
+    wt[i] = a.cw[c * 49 + k];
+  }
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    __syncthreads();
+    for (int i = tid; i < PH * PW; i += 256) {
+      const int y = i / PW - 3, x = i % PW - 3;
+      float v = 0.0f;
+      if (y >= 0 && y < 60 && x >= 0 && x < 90) {
+        if constexpr (U8) v = (float)((const uint8_t*)a.img)[(size_t)b * 5400 + y * 90 + x] / 255.0f;
+        else v = ((const float*)a.img)[(size_t)b * 5400 + y * 90 + x];
+      }
+      img[i] = v;
+    }
+    __syncthreads();
+    // the four bilinear taps of the conv output are blended on the input patch (both are linear)
+    for (int i = tid; i < 128 * 49; i += 256) {
+      const int t = i / 49, k = i - t * 49;
+      const int oy = t >> 4, ox = t & 15, ky = k / 7, kx = k - 7 * ky;
+      int y0, yp, x0, xp;
+      float ly, lx;
+      bilinear_src_dev(oy, 30.0f / 8.0f, 30, y0, yp, ly);
+      bilinear_src_dev(ox, 45.0f / 16.0f, 45, x0, xp, lx);
+      const float h1 = ly, h0 = 1.0f - ly, w1 = lx, w0 = 1.0f - lx;
+      const int iy = 2 * y0 + ky, ix = 2 * x0 + kx;   // (-3 conv padding) + (3 border) = 0
+      const float va = img[iy * PW + ix], vb = img[iy * PW + ix + 2 * xp];
+      const float vc = img[(iy + 2 * yp) * PW + ix], vd = img[(iy + 2 * yp) * PW + ix + 2 * xp];
+      pb[i] = h0 * (w0 * va + w1 * vb) + h1 * (w0 * vc + w1 * vd);
+    }
+    __syncthreads();
+    const int t = tid >> 1, half = tid & 1;
+    float acc[EC];
+#pragma unroll
+    for (int c = 0; c < EC; ++c) acc[c] = a.cb[half * EC + c];
+    for (int k = 0; k < 49; ++k) {
+      const float p = pb[t * 49 + k];
+      const float* w = wt + k * E + half * EC;
+#pragma unroll
+      for (int c = 0; c < EC; c += 4) {
+        const f32x4 w4 = *(const f32x4*)(w + c);
+        acc[c] = fmaf(p, w4.x, acc[c]);
+        acc[c + 1] = fmaf(p, w4.y, acc[c + 1]);
+        acc[c + 2] = fmaf(p, w4.z, acc[c + 2]);
+        acc[c + 3] = fmaf(p, w4.w, acc[c + 3]);
+      }
+    }
+    layernorm_lanes<E, 2>(acc, a.ln_w, a.ln_b, half * EC);
+    float* out = a.tokens + ((size_t)b * 128 + t) * E + half * EC;
+#pragma unroll
+    for (int c = 0; c < EC; c += 4) {
+      f32x4 v = {acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
+      *(f32x4*)(out + c) = v;
+    }
+  }
+}
+template <int E>
+constexpr int ita_tok_lds_bytes() { return (66 * 96 + 128 * 49 + 49 * E) * 4; }
+
+// ------------------------------------------------------------------ fusion tail
+struct ItaTailArgs {
+  const float* x2;     // (B,128,E) tokens after the encoder
+  const float* wT;     // [5E/4 * 9][12]: conv3x3 weights re-laid [c][ky][kx][o (9, padded to 12)]
+  const float* cb;     // [9]
+  float* feat;         // (B, 9*16*32) with row stride ld_feat
+  int ld_feat;
+  int B;
+};
+
+template <int E>
+__global__ __launch_bounds__(256) void ita_tail_kernel(const ItaTailArgs a) {
+  constexpr int XS = E + 1;              // token row stride (floats) in LDS
+  constexpr int FH = 18, FW = 34;        // 16x32 map with a zero border
+  constexpr int CH = 16;                 // channels per staged chunk
+  constexpr int NCHUNK = (E / 4 + E) / CH;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float* xs = (float*)lds;               // [128][XS]
+  float* fu = xs + 128 * XS;             // [CH][FH][FW]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < CH * FH * FW; i += 256) fu[i] = 0.0f;   // borders stay zero
+  const int py = tid >> 5, px = tid & 31;                        // outputs (py, px) and (py + 8, px)
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    __syncthreads();
+    for (int i = tid; i < 128 * E; i += 256) xs[(i / E) * XS + (i % E)] = a.x2[(size_t)b * 128 * E + i];
+    float acc0[9], acc1[9];
+#pragma unroll
+    for (int o = 0; o < 9; ++o) { acc0[o] = a.cb[o]; acc1[o] = a.cb[o]; }
+    for (int ch = 0; ch < NCHUNK; ++ch) {
+      __syncthreads();
+      for (int i = tid; i < CH * 512; i += 256) {
+        const int c = i >> 9, y = (i >> 5) & 15, x = i & 31;
+        float v;
+        if (ch * CH + c < E / 4) {           // PixelShuffle(2): out[c][2h+i][2w+j] = in[4c+2i+j][h][w]
+          const int cc = ch * CH + c;
+          v = xs[((y >> 1) * 16 + (x >> 1)) * XS + 4 * cc + 2 * (y & 1) + (x & 1)];
+        } else {                             // bilinear x2, align_corners=True
+          const int cc = ch * CH + c - E / 4;
+          const float sy = (7.0f / 15.0f) * (float)y, sx = (15.0f / 31.0f) * (float)x;
+          int y0 = (int)sy, x0 = (int)sx;
+          if (y0 > 7) y0 = 7;
+          if (x0 > 15) x0 = 15;
+          const int yp = y0 < 7 ? 1 : 0, xp = x0 < 15 ? 1 : 0;
+          const float h1 = sy - (float)y0, h0 = 1.0f - h1, w1 = sx - (float)x0, w0 = 1.0f - w1;
+          const float v00 = xs[(y0 * 16 + x0) * XS + cc], v01 = xs[(y0 * 16 + x0 + xp) * XS + cc];
+          const float v10 = xs[((y0 + yp) * 16 + x0) * XS + cc], v11 = xs[((y0 + yp) * 16 + x0 + xp) * XS + cc];
+          v = h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11);
+        }
+        fu[(c * FH + y + 1) * FW + x + 1] = v;
+      }
+      __syncthreads();
+      for (int c = 0; c < CH; ++c) {
+        const float* f = fu + c * FH * FW;
+        const float* w = a.wT + (size_t)((ch * CH + c) * 9) * 12;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const float v0 = f[(py + ky) * FW + px + kx], v1 = f[(py + 8 + ky) * FW + px + kx];
+            const float* wk = w + (ky * 3 + kx) * 12;
+#pragma unroll
+            for (int o = 0; o < 9; ++o) {
+              acc0[o] = fmaf(v0, wk[o], acc0[o]);
+              acc1[o] = fmaf(v1, wk[o], acc1[o]);
+            }
+          }
+      }
+    }
+    float* out = a.feat + (size_t)b * a.ld_feat;
+#pragma unroll
+    for (int o = 0; o < 9; ++o) {
+      out[o * 512 + py * 32 + px] = acc0[o];
+      out[o * 512 + (py + 8) * 32 + px] = acc1[o];
+    }
+  }
+}
+template <int E>
+constexpr int ita_tail_lds_bytes() { return (128 * (E + 1) + 16 * 18 * 34) * 4; }
+
+// ------------------------------------------------------------------ f32 GEMM (NT) on f32 MFMA
+// C[m][n] = bias[n] + sum_k A[m][k] * W[n][k], k ascending in one chain per output.
+// Workgroup = 4 waves as 2(M) x 2(N); wave tile 16(M) x 32(N) = two 16x16x4 accumulators;
+// workgroup tile 32 x 64; K staged through LDS 32 columns at a time.  N % 64 == 0, K % 32 == 0.
+struct ItaGemmArgs {
+  const float* A; int lda;
+  const float* W; int ldw;
+  const float* bias;
+  float* C; int ldc;
+  int M, N, K;
+};
+
+__global__ __launch_bounds__(256) void ita_gemm_f32_kernel(const ItaGemmArgs g) {
+  constexpr int LD = 36;
+  __shared__ __attribute__((aligned(16))) float As[32 * LD];
+  __shared__ __attribute__((aligned(16))) float Ws[64 * LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 64;
+  const int r = lane & 15, kq = lane >> 4;
+  // loader mapping: one float4 of A, two of W per thread per K-tile
+  const int lrow = tid >> 3, lk = (tid & 7) * 4;
+  const int arow = min(m0 + lrow, g.M - 1);
+  const float* ap = g.A + (size_t)arow * g.lda + lk;
+  const float* wp0 = g.W + (size_t)(n0 + lrow) * g.ldw + lk;
+  const float* wp1 = g.W + (size_t)(n0 + 32 + lrow) * g.ldw + lk;
+  f32x4 acc0, acc1;
+  {
+    const float b0 = g.bias ? g.bias[n0 + wn * 32 + r] : 0.0f;
+    const float b1 = g.bias ? g.bias[n0 + wn * 32 + 16 + r] : 0.0f;
+    acc0 = (f32x4){b0, b0, b0, b0};
+    acc1 = (f32x4){b1, b1, b1, b1};
+  }
+  f32x4 ra = *(const f32x4*)ap, rw0 = *(const f32x4*)wp0, rw1 = *(const f32x4*)wp1;
+  for (int k0 = 0; k0 < g.K; k0 += 32) {
+    __syncthreads();
+    *(f32x4*)(As + lrow * LD + lk) = ra;
+    *(f32x4*)(Ws + lrow * LD + lk) = rw0;
+    *(f32x4*)(Ws + (32 + lrow) * LD + lk) = rw1;
+    __syncthreads();
+    if (k0 + 32 < g.K) {
+      ra = *(const f32x4*)(ap + k0 + 32);
+      rw0 = *(const f32x4*)(wp0 + k0 + 32);
+      rw1 = *(const f32x4*)(wp1 + k0 + 32);
+    }
+    const float* as = As + (wm * 16 + r) * LD + kq;
+    const float* ws0 = Ws + (wn * 32 + r) * LD + kq;
+    const float* ws1 = Ws + (wn * 32 + 16 + r) * LD + kq;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float av = as[4 * s];
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, ws0[4 * s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, ws1[4 * s], acc1, 0, 0, 0);
+    }
+  }
+  // C layout: col = lane&15, row = 4*(lane>>4) + i
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 16 + 4 * kq + i;
+    if (m < g.M) {
+      g.C[(size_t)m * g.ldc + n0 + wn * 32 + r] = acc0[i];
+      g.C[(size_t)m * g.ldc + n0 + wn * 32 + 16 + r] = acc1[i];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ LSTM glue
+// cat0[b] = [dec(512, written by the decoder GEMM) | desvel/10 | quat(4) | h_in[0][b](128) | 0-pad] (K0P wide)
+// cat1[b] = [h_out[0][b] (written by layer 0) | h_in[1][b]],  cat2[b] likewise
+struct ItaLstmPrepArgs {
+  const float *desvel, *quat, *h_in;   // (B), (B,4), (3,B,128)
+  float *cat0, *cat1, *cat2;
+  int k0p;                             // padded width of cat0 (672)
+  int B;
+};
+__global__ void ita_lstm_prep_kernel(const ItaLstmPrepArgs a) {
+  const int b = blockIdx.x, t = threadIdx.x;   // 256 threads
+  if (b >= a.B) return;
+  float* c0 = a.cat0 + (size_t)b * a.k0p;
+  if (t == 0) c0[512] = a.desvel[b] / 10.0f;
+  if (t >= 1 && t < 5) c0[512 + t] = a.quat[(size_t)b * 4 + t - 1];
+  if (t < 128) {
+    c0[517 + t] = a.h_in[(size_t)b * 128 + t];
+    a.cat1[(size_t)b * 256 + 128 + t] = a.h_in[((size_t)a.B + b) * 128 + t];
+    a.cat2[(size_t)b * 256 + 128 + t] = a.h_in[((size_t)2 * a.B + b) * 128 + t];
+  }
+  if (t >= 128 && 517 + t < a.k0p) c0[517 + t] = 0.0f;
+}
+
+struct ItaLstmPointArgs {
+  const float* gates;   // (B,512) i,f,g,o pre-activations (biases included)
+  const float* c_in;    // (B,128) this layer
+  float *h_out, *c_out; // (B,128) this layer
+  float* next_in;       // next layer's concat buffer (row stride next_ld) or null
+  int next_ld;
+  int B;
+};
+__global__ void ita_lstm_point_kernel(const ItaLstmPointArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.B * 128) return;
+  const int b = idx >> 7, j = idx & 127;
+  const float* g = a.gates + (size_t)b * 512;
+  const float ig = ita_sigmoid(g[j]), fg = ita_sigmoid(g[128 + j]), gg = ita_tanh(g[256 + j]),
+              og = ita_sigmoid(g[384 + j]);
+  const float c = fmaf(fg, a.c_in[idx], ig * gg);
+  const float h = og * ita_tanh(c);
+  a.c_out[idx] = c;
+  a.h_out[idx] = h;
+  if (a.next_in) a.next_in[(size_t)b * a.next_ld + j] = h;
+}
+
+// fc 128 -> 3
+__global__ void ita_fc_kernel(const float* __restrict__ h, const float* __restrict__ w, const float* __restrict__ bias,
+                              float* __restrict__ vel, int B) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * 3) return;
+  const int b = idx / 3, o = idx - 3 * b;
+  float acc = bias[o];
+  for (int k = 0; k < 128; ++k) acc = fmaf(h[(size_t)b * 128 + k], w[o * 128 + k], acc);
+  vel[idx] = acc;
+}

@@ -1,0 +1,594 @@
+// ita_plugin.hip -- C ABI (include/ita_mi355x.h) over the gfx950 kernels.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off
+//        -I include  csrc/ita_plugin.hip -o csrc/libita_mi355x.so
+// (the iree_runtime_plugin.cmake equivalent is plugin/ita_runtime_plugin.cmake).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/ita_mi355x.h"
+#include "../../include/ita_weights.h"
+#include "ita_f32_kernels.h"
+#include "ita_int8_kernels.h"
+
+namespace {
+
+thread_local int tl_err = ITA_OK;
+thread_local std::string tl_msg;
+
+int fail(int code, const std::string& msg) {
+  tl_err = code;
+  tl_msg = msg;
+  return code;
+}
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      return fail(ITA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                \
+  } while (0)
+
+constexpr int K0P = 672;   // LSTM layer-0 concat width 517 + 128 = 645, zero padded to a multiple of 32
+
+struct Layer {
+  const int8_t *wq, *wk, *wv, *wo, *w1, *w2;
+  const int32_t *bq, *bk, *bv, *bo, *b1, *b2;
+  float ascal[ITA_A_NSCAL], fscal[ITA_F_NSCAL];
+  const float *n1w, *n1b, *n2w, *n2b;
+};
+
+}  // namespace
+
+struct ita_context {
+  int device = 0;
+  int num_cus = 256;
+  bool loaded = false;
+  ita_blob_header hdr{};
+  std::vector<char> hblob;
+  char* dblob = nullptr;
+  std::vector<Layer> layers;
+  // float layers (device pointers into dblob)
+  const float *tok_w = nullptr, *tok_b = nullptr, *tok_lw = nullptr, *tok_lb = nullptr;
+  const float *tail_b = nullptr, *dec_w = nullptr, *dec_b = nullptr, *fc_w = nullptr, *fc_b = nullptr;
+  // derived device buffers
+  float* tail_wT = nullptr;
+  float* wcat[3] = {nullptr, nullptr, nullptr};
+  float* bsum[3] = {nullptr, nullptr, nullptr};
+  // workspace
+  int cap = 0;
+  float *bufA = nullptr, *bufB = nullptr, *cat0 = nullptr, *cat1 = nullptr, *cat2 = nullptr, *gates = nullptr,
+        *feat = nullptr;
+  // staging for the host-buffer drop-in symbols
+  float *dsp_in = nullptr, *dsp_out = nullptr;
+  std::vector<float> dsp_host;
+};
+
+namespace {
+
+std::mutex g_bind_mu;
+ita_handle g_bound = nullptr;
+int g_bound_layer = 0;
+int g_bound_dtype = ITA_DISPATCH_F16;
+
+template <typename T>
+const T* dptr(ita_context* c, const char* name, bool required, bool* ok) {
+  const ita_blob_entry* e = ita_blob_find(c->hblob.data(), c->hblob.size(), name);
+  if (!e) {
+    if (required) *ok = false;
+    return nullptr;
+  }
+  return (const T*)(c->dblob + e->offset);
+}
+template <typename T>
+const T* hptr(ita_context* c, const char* name) {
+  const ita_blob_entry* e = ita_blob_find(c->hblob.data(), c->hblob.size(), name);
+  return e ? (const T*)(c->hblob.data() + e->offset) : nullptr;
+}
+
+void free_weights(ita_context* c) {
+  if (c->dblob) (void)hipFree(c->dblob);
+  if (c->tail_wT) (void)hipFree(c->tail_wT);
+  for (int l = 0; l < 3; ++l) {
+    if (c->wcat[l]) (void)hipFree(c->wcat[l]);
+    if (c->bsum[l]) (void)hipFree(c->bsum[l]);
+    c->wcat[l] = c->bsum[l] = nullptr;
+  }
+  c->dblob = nullptr;
+  c->tail_wT = nullptr;
+  c->loaded = false;
+}
+
+void free_workspace(ita_context* c) {
+  float** bufs[] = {&c->bufA, &c->bufB, &c->cat0, &c->cat1, &c->cat2, &c->gates, &c->feat};
+  for (float** b : bufs) {
+    if (*b) (void)hipFree(*b);
+    *b = nullptr;
+  }
+  c->cap = 0;
+}
+
+int ensure_workspace(ita_context* c, int B) {
+  if (B <= c->cap) return ITA_OK;
+  free_workspace(c);
+  const size_t E = (size_t)c->hdr.E;
+  HIPCHK(hipMalloc(&c->bufA, sizeof(float) * B * 128 * E));
+  HIPCHK(hipMalloc(&c->bufB, sizeof(float) * B * 128 * E));
+  HIPCHK(hipMalloc(&c->feat, sizeof(float) * (size_t)B * 4608));
+  HIPCHK(hipMalloc(&c->cat0, sizeof(float) * (size_t)B * K0P));
+  HIPCHK(hipMalloc(&c->cat1, sizeof(float) * (size_t)B * 256));
+  HIPCHK(hipMalloc(&c->cat2, sizeof(float) * (size_t)B * 256));
+  HIPCHK(hipMalloc(&c->gates, sizeof(float) * (size_t)B * 512));
+  c->cap = B;
+  return ITA_OK;
+}
+
+template <typename K>
+int set_lds(K kernel, int bytes) {
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  return ITA_OK;
+}
+
+int check(ita_handle h, int batch, bool need_weights = true) {
+  if (!h) return fail(ITA_ERR_INVALID_ARG, "null handle");
+  if (batch <= 0) return fail(ITA_ERR_INVALID_ARG, "batch must be positive");
+  if (need_weights && !h->loaded) return fail(ITA_ERR_NO_WEIGHTS, "ita_load_weights has not been called");
+  HIPCHK(hipSetDevice(h->device));
+  return ITA_OK;
+}
+
+ItaMhaArgs mha_args(ita_context* c, int layer, const float* x, float* y, int B, bool fuse, const ita_mha_taps* t) {
+  const Layer& L = c->layers[layer];
+  ItaMhaArgs a{};
+  a.x = x; a.y = y;
+  a.wq = L.wq; a.wk = L.wk; a.wv = L.wv; a.wo = L.wo;
+  a.bq = L.bq; a.bk = L.bk; a.bv = L.bv; a.bo = L.bo;
+  a.inv_sx = L.ascal[ITA_A_INV_SX]; a.mq = L.ascal[ITA_A_MQ]; a.mk = L.ascal[ITA_A_MK]; a.mv = L.ascal[ITA_A_MV];
+  a.ml = L.ascal[ITA_A_ML]; a.mc = L.ascal[ITA_A_MC]; a.mo = L.ascal[ITA_A_MO]; a.so = L.ascal[ITA_A_SO];
+  a.ln_w = L.n1w; a.ln_b = L.n1b;
+  a.B = B; a.fuse_ln = fuse ? 1 : 0;
+  if (t) {
+    a.t_xq = t->x_q; a.t_Q = t->Q; a.t_K = t->K; a.t_V = t->V; a.t_logits = t->logits; a.t_probs = t->probs;
+    a.t_ctx = t->ctx; a.t_out = t->out_q;
+  }
+  return a;
+}
+
+int launch_mha(ita_context* c, int layer, const float* x, float* y, int B, bool fuse, const ita_mha_taps* t,
+               hipStream_t s) {
+  if (fuse && !c->layers[layer].n1w) return fail(ITA_ERR_BAD_BLOB, "norm1 parameters missing from the blob");
+  const ItaMhaArgs a = mha_args(c, layer, x, y, B, fuse, t);
+  const int grid = B < c->num_cus ? B : c->num_cus;
+  if (c->hdr.E == 64) {
+    hipLaunchKernelGGL(ita_mha_kernel<64>, dim3(grid), dim3(512), ItaMhaLds<64>::TOTAL, s, a);
+  } else {
+    hipLaunchKernelGGL(ita_mha_kernel<128>, dim3(grid), dim3(512), ItaMhaLds<128>::TOTAL, s, a);
+  }
+  HIPCHK(hipGetLastError());
+  return ITA_OK;
+}
+
+int launch_ffn(ita_context* c, int layer, const float* x, float* y, int B, bool fuse, const ita_ffn_taps* t,
+               hipStream_t s) {
+  const Layer& L = c->layers[layer];
+  if (fuse && !L.n2w) return fail(ITA_ERR_BAD_BLOB, "norm2 parameters missing from the blob");
+  ItaFfnArgs a{};
+  a.x = x; a.y = y; a.w1 = L.w1; a.w2 = L.w2; a.b1 = L.b1; a.b2 = L.b2;
+  a.inv_sx = L.fscal[ITA_F_INV_SX]; a.m1 = L.fscal[ITA_F_M1]; a.m2 = L.fscal[ITA_F_M2]; a.s2 = L.fscal[ITA_F_S2];
+  a.ln_w = L.n2w; a.ln_b = L.n2b; a.B = B; a.fuse_ln = fuse ? 1 : 0;
+  if (t) { a.t_xq = t->x_q; a.t_h = t->h; a.t_out = t->out_q; }
+  const int grid = B < 2 * c->num_cus ? B : 2 * c->num_cus;
+  if (c->hdr.E == 64) {
+    hipLaunchKernelGGL(ita_ffn_kernel<64>, dim3(grid), dim3(512), ItaFfnLds<64>::TOTAL, s, a);
+  } else {
+    hipLaunchKernelGGL(ita_ffn_kernel<128>, dim3(grid), dim3(512), ItaFfnLds<128>::TOTAL, s, a);
+  }
+  HIPCHK(hipGetLastError());
+  return ITA_OK;
+}
+
+int launch_tokenizer(ita_context* c, const void* img, int dtype, float* tokens, int B, hipStream_t s) {
+  if (!c->tok_w) return fail(ITA_ERR_BAD_BLOB, "tokenizer parameters missing from the blob");
+  ItaTokArgs a{img, c->tok_w, c->tok_b, c->tok_lw, c->tok_lb, tokens, B};
+  const int grid = B < 2 * c->num_cus ? B : 2 * c->num_cus;
+  const bool u8 = dtype == ITA_IMAGE_U8;
+  if (c->hdr.E == 64) {
+    if (u8) hipLaunchKernelGGL((ita_tokenizer_kernel<64, true>), dim3(grid), dim3(256), ita_tok_lds_bytes<64>(), s, a);
+    else hipLaunchKernelGGL((ita_tokenizer_kernel<64, false>), dim3(grid), dim3(256), ita_tok_lds_bytes<64>(), s, a);
+  } else {
+    if (u8) hipLaunchKernelGGL((ita_tokenizer_kernel<128, true>), dim3(grid), dim3(256), ita_tok_lds_bytes<128>(), s, a);
+    else hipLaunchKernelGGL((ita_tokenizer_kernel<128, false>), dim3(grid), dim3(256), ita_tok_lds_bytes<128>(), s, a);
+  }
+  HIPCHK(hipGetLastError());
+  return ITA_OK;
+}
+
+int launch_tail(ita_context* c, const float* x, float* feat, int ld, int B, hipStream_t s) {
+  if (!c->tail_wT) return fail(ITA_ERR_BAD_BLOB, "fusion-tail parameters missing from the blob");
+  if (c->hdr.E != 64) return fail(ITA_ERR_UNSUPPORTED, "fusion tail is built for E = 64 (ITAViTLSTM)");
+  ItaTailArgs a{x, c->tail_wT, c->tail_b, feat, ld, B};
+  const int grid = B < 2 * c->num_cus ? B : 2 * c->num_cus;
+  hipLaunchKernelGGL(ita_tail_kernel<64>, dim3(grid), dim3(256), ita_tail_lds_bytes<64>(), s, a);
+  HIPCHK(hipGetLastError());
+  return ITA_OK;
+}
+
+int launch_gemm(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N,
+                int K, hipStream_t s) {
+  if (N % 64 || K % 32) return fail(ITA_ERR_UNSUPPORTED, "gemm needs N % 64 == 0 and K % 32 == 0");
+  ItaGemmArgs g{A, lda, W, ldw, bias, C, ldc, M, N, K};
+  hipLaunchKernelGGL(ita_gemm_f32_kernel, dim3(N / 64, (M + 31) / 32), dim3(256), 0, s, g);
+  HIPCHK(hipGetLastError());
+  return ITA_OK;
+}
+
+int dispatch_host(const uint16_t* in, uint16_t* out, bool ffn);
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" {
+
+int ita_abi_version(void) { return ITA_MI355X_ABI_VERSION; }
+int ita_last_error(void) { return tl_err; }
+const char* ita_error_string(void) { return tl_msg.c_str(); }
+
+int ita_create(ita_handle* out, int device_ordinal) {
+  if (!out) return fail(ITA_ERR_INVALID_ARG, "out is null");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(ITA_ERR_NO_DEVICE, "no HIP device visible");
+  int dev = device_ordinal;
+  if (dev < 0) HIPCHK(hipGetDevice(&dev));
+  if (dev >= n) return fail(ITA_ERR_INVALID_ARG, "device ordinal out of range");
+  HIPCHK(hipSetDevice(dev));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, dev));
+  ita_context* c = new ita_context();
+  c->device = dev;
+  c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  int rc = ITA_OK;
+  if ((rc = set_lds(ita_mha_kernel<64>, ItaMhaLds<64>::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_mha_kernel<128>, ItaMhaLds<128>::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_ffn_kernel<64>, ItaFfnLds<64>::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_ffn_kernel<128>, ItaFfnLds<128>::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_tokenizer_kernel<64, true>, ita_tok_lds_bytes<64>()))) { delete c; return rc; }
+  if ((rc = set_lds(ita_tokenizer_kernel<64, false>, ita_tok_lds_bytes<64>()))) { delete c; return rc; }
+  if ((rc = set_lds(ita_tokenizer_kernel<128, true>, ita_tok_lds_bytes<128>()))) { delete c; return rc; }
+  if ((rc = set_lds(ita_tokenizer_kernel<128, false>, ita_tok_lds_bytes<128>()))) { delete c; return rc; }
+  if ((rc = set_lds(ita_tail_kernel<64>, ita_tail_lds_bytes<64>()))) { delete c; return rc; }
+  *out = c;
+  return ITA_OK;
+}
+
+int ita_destroy(ita_handle h) {
+  if (!h) return fail(ITA_ERR_INVALID_ARG, "null handle");
+  {
+    std::lock_guard<std::mutex> g(g_bind_mu);
+    if (g_bound == h) g_bound = nullptr;
+  }
+  (void)hipSetDevice(h->device);
+  free_weights(h);
+  free_workspace(h);
+  if (h->dsp_in) (void)hipFree(h->dsp_in);
+  if (h->dsp_out) (void)hipFree(h->dsp_out);
+  delete h;
+  return ITA_OK;
+}
+
+int ita_load_weights(ita_handle h, const void* blob, size_t nbytes) {
+  if (!h || !blob) return fail(ITA_ERR_INVALID_ARG, "null argument");
+  if (nbytes < sizeof(ita_blob_header) || memcmp(blob, ITA_BLOB_MAGIC, 8) != 0)
+    return fail(ITA_ERR_BAD_BLOB, "not an ITAW0001 blob");
+  HIPCHK(hipSetDevice(h->device));
+  ita_blob_header hdr;
+  memcpy(&hdr, blob, sizeof hdr);
+  if (hdr.n_tensors < 0 || sizeof(hdr) + (size_t)hdr.n_tensors * sizeof(ita_blob_entry) > nbytes)
+    return fail(ITA_ERR_BAD_BLOB, "tensor table exceeds the blob");
+  if ((hdr.E != 64 && hdr.E != 128) || hdr.S != 128 || hdr.P != 192 || hdr.F != 256 || hdr.H != 1 ||
+      hdr.num_layers < 1 || hdr.num_layers > 16)
+    return fail(ITA_ERR_UNSUPPORTED, "kernels are built for E in {64,128}, S=128, P=192, F=256, H=1");
+  {
+    const ita_blob_entry* e = (const ita_blob_entry*)((const char*)blob + sizeof(hdr));
+    for (int i = 0; i < hdr.n_tensors; ++i)
+      if (e[i].offset < 0 || e[i].nbytes < 0 || (size_t)e[i].offset + (size_t)e[i].nbytes > nbytes ||
+          (e[i].offset & 15))
+        return fail(ITA_ERR_BAD_BLOB, "tensor out of bounds or misaligned");
+  }
+  free_weights(h);
+  free_workspace(h);
+  h->hdr = hdr;
+  h->hblob.assign((const char*)blob, (const char*)blob + nbytes);
+  HIPCHK(hipMalloc(&h->dblob, nbytes));
+  HIPCHK(hipMemcpy(h->dblob, blob, nbytes, hipMemcpyHostToDevice));
+  bool ok = true;
+  h->layers.assign(hdr.num_layers, Layer{});
+  char nm[40];
+  auto expect = [&](const char* name, size_t bytes) {
+    const ita_blob_entry* e = ita_blob_find(h->hblob.data(), h->hblob.size(), name);
+    if (e && (size_t)e->nbytes != bytes) ok = false;
+  };
+  const size_t E = hdr.E, P = hdr.P, F = hdr.F;
+  for (int i = 0; i < hdr.num_layers; ++i) {
+    Layer& L = h->layers[i];
+#define NM(fmt) (snprintf(nm, sizeof nm, fmt, i), nm)
+    expect(NM("attn%d.wq"), P * E); expect(NM("attn%d.wo"), E * P); expect(NM("attn%d.bq"), P * 4);
+    expect(NM("attn%d.bo"), E * 4); expect(NM("ffn%d.w1"), F * E); expect(NM("ffn%d.w2"), E * F);
+    expect(NM("attn%d.scal"), ITA_A_NSCAL * 4); expect(NM("ffn%d.scal"), ITA_F_NSCAL * 4);
+    L.wq = dptr<int8_t>(h, NM("attn%d.wq"), true, &ok); L.wk = dptr<int8_t>(h, NM("attn%d.wk"), true, &ok);
+    L.wv = dptr<int8_t>(h, NM("attn%d.wv"), true, &ok); L.wo = dptr<int8_t>(h, NM("attn%d.wo"), true, &ok);
+    L.bq = dptr<int32_t>(h, NM("attn%d.bq"), true, &ok); L.bk = dptr<int32_t>(h, NM("attn%d.bk"), true, &ok);
+    L.bv = dptr<int32_t>(h, NM("attn%d.bv"), true, &ok); L.bo = dptr<int32_t>(h, NM("attn%d.bo"), true, &ok);
+    L.w1 = dptr<int8_t>(h, NM("ffn%d.w1"), true, &ok); L.w2 = dptr<int8_t>(h, NM("ffn%d.w2"), true, &ok);
+    L.b1 = dptr<int32_t>(h, NM("ffn%d.b1"), true, &ok); L.b2 = dptr<int32_t>(h, NM("ffn%d.b2"), true, &ok);
+    const float* as = hptr<float>(h, NM("attn%d.scal"));
+    const float* fs = hptr<float>(h, NM("ffn%d.scal"));
+    if (!as || !fs) { ok = false; break; }
+    memcpy(L.ascal, as, sizeof L.ascal);
+    memcpy(L.fscal, fs, sizeof L.fscal);
+    L.n1w = dptr<float>(h, NM("norm1_%d.w"), false, &ok); L.n1b = dptr<float>(h, NM("norm1_%d.b"), false, &ok);
+    L.n2w = dptr<float>(h, NM("norm2_%d.w"), false, &ok); L.n2b = dptr<float>(h, NM("norm2_%d.b"), false, &ok);
+#undef NM
+  }
+  if (!ok) { free_weights(h); return fail(ITA_ERR_BAD_BLOB, "a required int8 block tensor is missing or mis-sized"); }
+  h->tok_w = dptr<float>(h, "tok.conv_w", false, &ok); h->tok_b = dptr<float>(h, "tok.conv_b", false, &ok);
+  h->tok_lw = dptr<float>(h, "tok.ln_w", false, &ok); h->tok_lb = dptr<float>(h, "tok.ln_b", false, &ok);
+  h->tail_b = dptr<float>(h, "tail.conv_b", false, &ok);
+  h->dec_w = dptr<float>(h, "dec.w", false, &ok); h->dec_b = dptr<float>(h, "dec.b", false, &ok);
+  h->fc_w = dptr<float>(h, "fc.w", false, &ok); h->fc_b = dptr<float>(h, "fc.b", false, &ok);
+  // derived: conv3x3 weights re-laid [c][ky][kx][o -> 12] so one tap's 9 output weights are contiguous
+  if (const float* cw = hptr<float>(h, "tail.conv_w")) {
+    const int cin = hdr.E / 4 + hdr.E;
+    std::vector<float> wT((size_t)cin * 9 * 12, 0.0f);
+    for (int o = 0; o < 9; ++o)
+      for (int c = 0; c < cin; ++c)
+        for (int k = 0; k < 9; ++k) wT[((size_t)c * 9 + k) * 12 + o] = cw[((size_t)o * cin + c) * 9 + k];
+    HIPCHK(hipMalloc(&h->tail_wT, wT.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(h->tail_wT, wT.data(), wT.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  // derived: LSTM [W_ih | W_hh] concatenated along k (layer 0 zero padded to K0P), b_ih + b_hh
+  if (hptr<float>(h, "lstm.w_ih0")) {
+    for (int l = 0; l < 3; ++l) {
+      char a[32], b[32], ci[32], d[32];
+      snprintf(a, sizeof a, "lstm.w_ih%d", l); snprintf(b, sizeof b, "lstm.w_hh%d", l);
+      snprintf(ci, sizeof ci, "lstm.b_ih%d", l); snprintf(d, sizeof d, "lstm.b_hh%d", l);
+      const float *wih = hptr<float>(h, a), *whh = hptr<float>(h, b), *bih = hptr<float>(h, ci), *bhh = hptr<float>(h, d);
+      if (!wih || !whh || !bih || !bhh) { free_weights(h); return fail(ITA_ERR_BAD_BLOB, "incomplete LSTM parameters"); }
+      const int in = l == 0 ? 517 : 128, kp = l == 0 ? K0P : 256;
+      std::vector<float> wc((size_t)512 * kp, 0.0f), bs(512);
+      for (int j = 0; j < 512; ++j) {
+        memcpy(&wc[(size_t)j * kp], wih + (size_t)j * in, sizeof(float) * in);
+        memcpy(&wc[(size_t)j * kp + in], whh + (size_t)j * 128, sizeof(float) * 128);
+        bs[j] = bih[j] + bhh[j];
+      }
+      HIPCHK(hipMalloc(&h->wcat[l], wc.size() * sizeof(float)));
+      HIPCHK(hipMemcpy(h->wcat[l], wc.data(), wc.size() * sizeof(float), hipMemcpyHostToDevice));
+      HIPCHK(hipMalloc(&h->bsum[l], 512 * sizeof(float)));
+      HIPCHK(hipMemcpy(h->bsum[l], bs.data(), 512 * sizeof(float), hipMemcpyHostToDevice));
+    }
+  }
+  h->loaded = true;
+  return ITA_OK;
+}
+
+int ita_reserve(ita_handle h, int max_batch) {
+  int rc = check(h, max_batch);
+  if (rc) return rc;
+  return ensure_workspace(h, max_batch);
+}
+
+int ita_get_dims(ita_handle h, int* E, int* S, int* P, int* F, int* H, int* num_layers) {
+  if (!h || !h->loaded) return fail(ITA_ERR_NO_WEIGHTS, "no weights loaded");
+  if (E) *E = h->hdr.E;
+  if (S) *S = h->hdr.S;
+  if (P) *P = h->hdr.P;
+  if (F) *F = h->hdr.F;
+  if (H) *H = h->hdr.H;
+  if (num_layers) *num_layers = h->hdr.num_layers;
+  return ITA_OK;
+}
+
+int ita_mha_int8_taps(ita_handle h, int layer, const float* x, float* y, int batch, const ita_mha_taps* taps,
+                      void* stream) {
+  int rc = check(h, batch);
+  if (rc) return rc;
+  if (!x || !y || layer < 0 || layer >= h->hdr.num_layers) return fail(ITA_ERR_INVALID_ARG, "bad pointer or layer");
+  return launch_mha(h, layer, x, y, batch, false, taps, (hipStream_t)stream);
+}
+int ita_mha_int8(ita_handle h, int layer, const float* x, float* y, int batch, void* stream) {
+  return ita_mha_int8_taps(h, layer, x, y, batch, nullptr, stream);
+}
+
+int ita_ffn_int8_taps(ita_handle h, int layer, const float* x, float* y, int batch, const ita_ffn_taps* taps,
+                      void* stream) {
+  int rc = check(h, batch);
+  if (rc) return rc;
+  if (!x || !y || layer < 0 || layer >= h->hdr.num_layers) return fail(ITA_ERR_INVALID_ARG, "bad pointer or layer");
+  return launch_ffn(h, layer, x, y, batch, false, taps, (hipStream_t)stream);
+}
+int ita_ffn_int8(ita_handle h, int layer, const float* x, float* y, int batch, void* stream) {
+  return ita_ffn_int8_taps(h, layer, x, y, batch, nullptr, stream);
+}
+
+int ita_encoder_layer(ita_handle h, int layer, const float* x, float* y, int batch, void* stream) {
+  int rc = check(h, batch);
+  if (rc) return rc;
+  if (!x || !y || layer < 0 || layer >= h->hdr.num_layers) return fail(ITA_ERR_INVALID_ARG, "bad pointer or layer");
+  if ((rc = launch_mha(h, layer, x, y, batch, true, nullptr, (hipStream_t)stream))) return rc;
+  return launch_ffn(h, layer, y, y, batch, true, nullptr, (hipStream_t)stream);
+}
+
+int ita_tokenizer(ita_handle h, const void* image, int image_dtype, float* tokens, int batch, void* stream) {
+  int rc = check(h, batch);
+  if (rc) return rc;
+  if (!image || !tokens || (image_dtype != ITA_IMAGE_F32 && image_dtype != ITA_IMAGE_U8))
+    return fail(ITA_ERR_INVALID_ARG, "bad pointer or image dtype");
+  return launch_tokenizer(h, image, image_dtype, tokens, batch, (hipStream_t)stream);
+}
+
+int ita_fusion_tail(ita_handle h, const float* x, float* feat, int batch, void* stream) {
+  int rc = check(h, batch);
+  if (rc) return rc;
+  if (!x || !feat) return fail(ITA_ERR_INVALID_ARG, "null pointer");
+  return launch_tail(h, x, feat, 4608, batch, (hipStream_t)stream);
+}
+
+int ita_vitlstm_forward(ita_handle h, const void* image, int image_dtype, const float* desvel, const float* quat,
+                        const float* h_in, const float* c_in, float* vel, float* h_out, float* c_out, int batch,
+                        const ita_forward_taps* taps, void* stream) {
+  int rc = check(h, batch);
+  if (rc) return rc;
+  if (!image || !desvel || !quat || !h_in || !c_in || !vel || !h_out || !c_out)
+    return fail(ITA_ERR_INVALID_ARG, "null pointer");
+  if (image_dtype != ITA_IMAGE_F32 && image_dtype != ITA_IMAGE_U8) return fail(ITA_ERR_INVALID_ARG, "bad image dtype");
+  if (!h->hdr.has_tail || !h->dec_w || !h->wcat[0] || !h->fc_w)
+    return fail(ITA_ERR_BAD_BLOB, "blob holds no tail / decoder / LSTM parameters");
+  if ((rc = ensure_workspace(h, batch))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int B = batch;
+  const size_t tokb = sizeof(float) * (size_t)B * 128 * h->hdr.E;
+  if ((rc = launch_tokenizer(h, image, image_dtype, h->bufA, B, s))) return rc;
+  if (taps && taps->tokens) HIPCHK(hipMemcpyAsync(taps->tokens, h->bufA, tokb, hipMemcpyDeviceToDevice, s));
+  for (int l = 0; l < h->hdr.num_layers; ++l) {
+    if ((rc = launch_mha(h, l, h->bufA, h->bufB, B, true, nullptr, s))) return rc;
+    if (taps && taps->x1 && l == h->hdr.num_layers - 1)
+      HIPCHK(hipMemcpyAsync(taps->x1, h->bufB, tokb, hipMemcpyDeviceToDevice, s));
+    if ((rc = launch_ffn(h, l, h->bufB, h->bufA, B, true, nullptr, s))) return rc;
+  }
+  if (taps && taps->x2) HIPCHK(hipMemcpyAsync(taps->x2, h->bufA, tokb, hipMemcpyDeviceToDevice, s));
+  if ((rc = launch_tail(h, h->bufA, h->feat, 4608, B, s))) return rc;
+  if (taps && taps->feat)
+    HIPCHK(hipMemcpyAsync(taps->feat, h->feat, sizeof(float) * (size_t)B * 4608, hipMemcpyDeviceToDevice, s));
+  // decoder writes straight into the LSTM layer-0 concat buffer (columns 0..511)
+  if ((rc = launch_gemm(h->feat, 4608, h->dec_w, 4608, h->dec_b, h->cat0, K0P, B, 512, 4608, s))) return rc;
+  if (taps && taps->dec)
+    HIPCHK(hipMemcpy2DAsync(taps->dec, 512 * sizeof(float), h->cat0, K0P * sizeof(float), 512 * sizeof(float), B,
+                            hipMemcpyDeviceToDevice, s));
+  {
+    ItaLstmPrepArgs p{desvel, quat, h_in, h->cat0, h->cat1, h->cat2, K0P, B};
+    hipLaunchKernelGGL(ita_lstm_prep_kernel, dim3(B), dim3(256), 0, s, p);
+    HIPCHK(hipGetLastError());
+  }
+  float* cats[3] = {h->cat0, h->cat1, h->cat2};
+  const int kp[3] = {K0P, 256, 256};
+  for (int l = 0; l < 3; ++l) {
+    if ((rc = launch_gemm(cats[l], kp[l], h->wcat[l], kp[l], h->bsum[l], h->gates, 512, B, 512, kp[l], s))) return rc;
+    ItaLstmPointArgs p{h->gates, c_in + (size_t)l * B * 128, h_out + (size_t)l * B * 128, c_out + (size_t)l * B * 128,
+                       l < 2 ? cats[l + 1] : nullptr, 256, B};
+    hipLaunchKernelGGL(ita_lstm_point_kernel, dim3((B * 128 + 255) / 256), dim3(256), 0, s, p);
+    HIPCHK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(ita_fc_kernel, dim3((B * 3 + 63) / 64), dim3(64), 0, s, h_out + (size_t)2 * B * 128, h->fc_w,
+                     h->fc_b, vel, B);
+  HIPCHK(hipGetLastError());
+  return ITA_OK;
+}
+
+int ita_bind_dispatch(ita_handle h, int layer, int dispatch_dtype) {
+  if (!h || !h->loaded) return fail(ITA_ERR_NO_WEIGHTS, "bind needs a context with weights");
+  if (layer < 0 || layer >= h->hdr.num_layers) return fail(ITA_ERR_INVALID_ARG, "layer out of range");
+  if (dispatch_dtype != ITA_DISPATCH_F16 && dispatch_dtype != ITA_DISPATCH_F32)
+    return fail(ITA_ERR_INVALID_ARG, "bad dispatch dtype");
+  std::lock_guard<std::mutex> g(g_bind_mu);
+  g_bound = h;
+  g_bound_layer = layer;
+  g_bound_dtype = dispatch_dtype;
+  return ITA_OK;
+}
+
+void ITASelfAttention_workgroup(const uint16_t* input, uint16_t* output) { (void)dispatch_host(input, output, false); }
+void ITAFeedForward_workgroup(const uint16_t* input, uint16_t* output) { (void)dispatch_host(input, output, true); }
+
+void ITASelfAttention_workgroup_expanded(const uint16_t* b0, const uint16_t* b0_aligned, size_t b0_offset, size_t,
+                                         size_t, uint16_t* b1, uint16_t* b1_aligned, size_t b1_offset, size_t,
+                                         size_t) {
+  // memref descriptor: data = aligned + offset (elements); the reference falls back base -> aligned
+  const uint16_t* in = b0_aligned ? b0_aligned : b0;
+  uint16_t* out = b1_aligned ? b1_aligned : b1;
+  if (!in || !out) { fail(ITA_ERR_INVALID_ARG, "null binding"); return; }
+  size_t esz;
+  {
+    std::lock_guard<std::mutex> g(g_bind_mu);
+    esz = g_bound_dtype == ITA_DISPATCH_F16 ? 2 : 4;
+  }
+  in = (const uint16_t*)((const char*)in + b0_offset * esz);
+  out = (uint16_t*)((char*)out + b1_offset * esz);
+  (void)dispatch_host(in, out, false);
+}
+
+}  // extern "C"
+
+namespace {
+
+float half_to_float(uint16_t hbits) {
+  const uint32_t sign = (uint32_t)(hbits & 0x8000u) << 16;
+  uint32_t exp = (hbits >> 10) & 0x1fu, man = hbits & 0x3ffu, out;
+  if (exp == 0) {
+    if (man == 0) out = sign;
+    else {
+      exp = 127 - 15 + 1;
+      while (!(man & 0x400u)) { man <<= 1; --exp; }
+      out = sign | (exp << 23) | ((man & 0x3ffu) << 13);
+    }
+  } else if (exp == 31) out = sign | 0x7f800000u | (man << 13);
+  else out = sign | ((exp + 127 - 15) << 23) | (man << 13);
+  float f;
+  memcpy(&f, &out, 4);
+  return f;
+}
+uint16_t float_to_half(float f) {   // round to nearest even
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  const uint16_t sign = (uint16_t)((x >> 16) & 0x8000u);
+  const uint32_t absx = x & 0x7fffffffu;
+  if (absx >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (absx > 0x7f800000u ? 0x200u : 0));
+  if (absx >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);            // overflow -> inf
+  if (absx < 0x33000001u) return sign;                                    // underflow -> 0
+  int exp = (int)(absx >> 23) - 127 + 15;
+  uint32_t man = (absx & 0x7fffffu) | 0x800000u;
+  int shift = 13;
+  if (exp <= 0) { shift += 1 - exp; exp = 0; }
+  uint32_t hm = man >> shift;
+  const uint32_t rem = man & ((1u << shift) - 1), halfway = 1u << (shift - 1);
+  if (rem > halfway || (rem == halfway && (hm & 1))) ++hm;
+  uint32_t outv = exp > 0 ? (((uint32_t)exp << 10) + (hm - 0x400u)) : hm;   // mantissa carry bumps the exponent
+  return (uint16_t)(sign | outv);
+}
+
+// Host-buffer entry used by the reference's `void` symbols: 1 x 128 x E activation in, same out.
+int dispatch_host(const uint16_t* in, uint16_t* out, bool ffn) {
+  std::lock_guard<std::mutex> g(g_bind_mu);
+  ita_context* c = g_bound;
+  if (!c) return fail(ITA_ERR_NOT_BOUND, "ita_bind_dispatch has not been called");
+  if (!in || !out) return fail(ITA_ERR_INVALID_ARG, "null buffer");
+  HIPCHK(hipSetDevice(c->device));
+  const size_t n = (size_t)128 * c->hdr.E;
+  if (!c->dsp_in) {
+    HIPCHK(hipMalloc(&c->dsp_in, n * sizeof(float)));
+    HIPCHK(hipMalloc(&c->dsp_out, n * sizeof(float)));
+    c->dsp_host.resize(n);
+  }
+  const float* src = (const float*)in;
+  if (g_bound_dtype == ITA_DISPATCH_F16) {
+    for (size_t i = 0; i < n; ++i) c->dsp_host[i] = half_to_float(in[i]);
+    src = c->dsp_host.data();
+  }
+  HIPCHK(hipMemcpy(c->dsp_in, src, n * sizeof(float), hipMemcpyHostToDevice));
+  int rc = ffn ? launch_ffn(c, g_bound_layer, c->dsp_in, c->dsp_out, 1, false, nullptr, nullptr)
+               : launch_mha(c, g_bound_layer, c->dsp_in, c->dsp_out, 1, false, nullptr, nullptr);
+  if (rc) return rc;
+  if (g_bound_dtype == ITA_DISPATCH_F16) {
+    HIPCHK(hipMemcpy(c->dsp_host.data(), c->dsp_out, n * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) out[i] = float_to_half(c->dsp_host[i]);
+  } else {
+    HIPCHK(hipMemcpy(out, c->dsp_out, n * sizeof(float), hipMemcpyDeviceToHost));
+  }
+  tl_err = ITA_OK;
+  return ITA_OK;
+}
+
+}  // namespace

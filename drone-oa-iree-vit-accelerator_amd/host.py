@@ -1,0 +1,280 @@
+"""Host side of the MI355X ITA engine: ctypes binding of ``csrc/libita_mi355x.so`` (C ABI in
+include/ita_mi355x.h) and a mirror of the reference's model interface.
+
+PyTorch is used for device memory, streams and (in bench.py) torch.distributed only; all
+arithmetic happens in the HIP kernels behind the C ABI.  There is deliberately NO CPU or
+eager fallback: if the extension is missing or no GPU is visible, calls raise.
+
+Reference interface mirrored here (all paths relative to the reference repository):
+  ITALSTMNetVIT_QAT.forward(X)   models/ITA_single_layer_upsample_shuffle/QAT/model.py:93-132
+      X = [img (B,1,60,90), desvel (B,1), quat (B,4) | None, (h, c) | None] -> (vel (B,3), (h, c))
+  refine_inputs                  same file :22-31 (default quaternion, resize to 60x90)
+  ITASelfAttention_QAT / ITAFeedForward_QAT   models/ITA/QAT/layers.py:47-127
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional, Sequence
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_SO = os.path.join(_CSRC, "libita_mi355x.so")
+_REPO = os.path.dirname(_HERE)
+_LIB = None
+
+IMAGE_F32, IMAGE_U8 = 0, 1
+DISPATCH_F16, DISPATCH_F32 = 0, 1
+
+EXPORTED_SYMBOLS = (
+    "ita_abi_version", "ita_create", "ita_destroy", "ita_load_weights", "ita_reserve", "ita_get_dims",
+    "ita_last_error", "ita_error_string", "ita_mha_int8", "ita_mha_int8_taps", "ita_ffn_int8", "ita_ffn_int8_taps",
+    "ita_encoder_layer", "ita_tokenizer", "ita_fusion_tail", "ita_vitlstm_forward", "ita_bind_dispatch",
+    "ITASelfAttention_workgroup", "ITASelfAttention_workgroup_expanded", "ITAFeedForward_workgroup",
+)
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+               "-Wall", "-Wno-unused-function"]
+
+
+class ITAError(RuntimeError):
+    pass
+
+
+def build_extension(force: bool = False, verbose: bool = False) -> str:
+    """hipcc cross-compiles the plugin for gfx950 in-tree (works without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h"))]
+    srcs += [os.path.join(_REPO, "include", f) for f in ("ita_mi355x.h", "ita_weights.h")]
+    if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs):
+        return _SO
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-I", os.path.join(_REPO, "include"), os.path.join(_CSRC, "ita_plugin.hip"),
+                                   "-o", _SO]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return _SO
+
+
+class _MhaTaps(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x_q", "Q", "K", "V", "logits", "probs", "ctx", "out_q")]
+
+
+class _FfnTaps(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x_q", "h", "out_q")]
+
+
+class _FwdTaps(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("tokens", "x1", "x2", "feat", "dec")]
+
+
+def lib():
+    """Loads the C-ABI library; fails loudly when it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_SO):
+            raise ITAError(f"{_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)")
+        L = C.CDLL(_SO)
+        L.ita_error_string.restype = C.c_char_p
+        vp, i = C.c_void_p, C.c_int
+        L.ita_create.argtypes = [C.POINTER(vp), i]
+        L.ita_destroy.argtypes = [vp]
+        L.ita_load_weights.argtypes = [vp, vp, C.c_size_t]
+        L.ita_reserve.argtypes = [vp, i]
+        L.ita_get_dims.argtypes = [vp] + [C.POINTER(i)] * 6
+        L.ita_mha_int8.argtypes = [vp, i, vp, vp, i, vp]
+        L.ita_mha_int8_taps.argtypes = [vp, i, vp, vp, i, C.POINTER(_MhaTaps), vp]
+        L.ita_ffn_int8.argtypes = [vp, i, vp, vp, i, vp]
+        L.ita_ffn_int8_taps.argtypes = [vp, i, vp, vp, i, C.POINTER(_FfnTaps), vp]
+        L.ita_encoder_layer.argtypes = [vp, i, vp, vp, i, vp]
+        L.ita_tokenizer.argtypes = [vp, vp, i, vp, i, vp]
+        L.ita_fusion_tail.argtypes = [vp, vp, vp, i, vp]
+        L.ita_vitlstm_forward.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, vp, vp, i, C.POINTER(_FwdTaps), vp]
+        L.ita_bind_dispatch.argtypes = [vp, i, i]
+        L.ITASelfAttention_workgroup.argtypes = [vp, vp]
+        L.ITASelfAttention_workgroup.restype = None
+        L.ITAFeedForward_workgroup.argtypes = [vp, vp]
+        L.ITAFeedForward_workgroup.restype = None
+        L.ITASelfAttention_workgroup_expanded.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t] * 2
+        L.ITASelfAttention_workgroup_expanded.restype = None
+        _LIB = L
+    return _LIB
+
+
+def _chk(rc: int):
+    if rc != 0:
+        raise ITAError(f"ita status {rc}: {lib().ita_error_string().decode()}")
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _stream_ptr():
+    return C.c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+
+def _dev_f32(t, shape=None):
+    torch = _torch()
+    if not t.is_cuda:
+        raise ITAError("tensors handed to the ITA engine must live on the GPU (no CPU fallback)")
+    t = t.contiguous()
+    if t.dtype != torch.float32:
+        t = t.float()
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ITAError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+class Engine:
+    """One ita_context: weights resident on one GPU, stateless compute calls on caller-owned tensors."""
+
+    def __init__(self, blob: bytes, device: Optional[int] = None, reserve: int = 0):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise ITAError("no GPU visible: the ITA engine has no CPU path")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self._h = C.c_void_p()
+        _chk(lib().ita_create(C.byref(self._h), self.device))
+        buf = C.create_string_buffer(blob, len(blob))
+        _chk(lib().ita_load_weights(self._h, buf, len(blob)))
+        d = [C.c_int() for _ in range(6)]
+        _chk(lib().ita_get_dims(self._h, *[C.byref(x) for x in d]))
+        self.E, self.S, self.P, self.F, self.H, self.num_layers = [x.value for x in d]
+        if reserve:
+            _chk(lib().ita_reserve(self._h, reserve))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().ita_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- int8 blocks -------------------------------------------------------------------
+    def mha(self, x, layer: int = 0, taps: bool = False):
+        """ITASelfAttention_QAT.forward: (B,128,E) f32 -> (B,128,E) f32 [, dict of int tensors]."""
+        torch = _torch()
+        x = _dev_f32(x)
+        B = x.shape[0]
+        y = torch.empty_like(x)
+        if not taps:
+            _chk(lib().ita_mha_int8(self._h, layer, x.data_ptr(), y.data_ptr(), B, _stream_ptr()))
+            return y
+        mk = lambda *s, dt=torch.int8: torch.empty(s, dtype=dt, device=x.device)
+        t = dict(x_q=mk(B, 128, self.E), Q=mk(B, 128, self.P), K=mk(B, 128, self.P), V=mk(B, 128, self.P),
+                 logits=mk(B, 128, 128), probs=mk(B, 128, 128, dt=torch.uint8), ctx=mk(B, 128, self.P),
+                 out_q=mk(B, 128, self.E))
+        st = _MhaTaps(**{k: v.data_ptr() for k, v in t.items()})
+        _chk(lib().ita_mha_int8_taps(self._h, layer, x.data_ptr(), y.data_ptr(), B, C.byref(st), _stream_ptr()))
+        return y, t
+
+    def ffn(self, x, layer: int = 0, taps: bool = False):
+        torch = _torch()
+        x = _dev_f32(x)
+        B = x.shape[0]
+        y = torch.empty_like(x)
+        if not taps:
+            _chk(lib().ita_ffn_int8(self._h, layer, x.data_ptr(), y.data_ptr(), B, _stream_ptr()))
+            return y
+        mk = lambda *s: torch.empty(s, dtype=torch.int8, device=x.device)
+        t = dict(x_q=mk(B, 128, self.E), h=mk(B, 128, self.F), out_q=mk(B, 128, self.E))
+        st = _FfnTaps(**{k: v.data_ptr() for k, v in t.items()})
+        _chk(lib().ita_ffn_int8_taps(self._h, layer, x.data_ptr(), y.data_ptr(), B, C.byref(st), _stream_ptr()))
+        return y, t
+
+    def encoder_layer(self, x, layer: int = 0):
+        x = _dev_f32(x)
+        y = _torch().empty_like(x)
+        _chk(lib().ita_encoder_layer(self._h, layer, x.data_ptr(), y.data_ptr(), x.shape[0], _stream_ptr()))
+        return y
+
+    # ---- float stages ------------------------------------------------------------------
+    def tokenizer(self, img):
+        torch = _torch()
+        img, dt = self._image(img)
+        B = img.shape[0]
+        tok = torch.empty((B, 128, self.E), dtype=torch.float32, device=img.device)
+        _chk(lib().ita_tokenizer(self._h, img.data_ptr(), dt, tok.data_ptr(), B, _stream_ptr()))
+        return tok
+
+    def fusion_tail(self, x):
+        torch = _torch()
+        x = _dev_f32(x)
+        feat = torch.empty((x.shape[0], 4608), dtype=torch.float32, device=x.device)
+        _chk(lib().ita_fusion_tail(self._h, x.data_ptr(), feat.data_ptr(), x.shape[0], _stream_ptr()))
+        return feat
+
+    def _image(self, img):
+        torch = _torch()
+        if not img.is_cuda:
+            raise ITAError("image must be a GPU tensor")
+        if img.dtype == torch.uint8:
+            img = img.reshape(-1, 60, 90).contiguous()
+            return img, IMAGE_U8
+        img = img.float()
+        if img.shape[-2:] != (60, 90):   # refine_inputs: bilinear resize, align_corners=False (QAT/model.py:29-30)
+            img = torch.nn.functional.interpolate(img.reshape(-1, 1, *img.shape[-2:]), size=(60, 90),
+                                                  mode="bilinear", align_corners=False)
+        return img.reshape(-1, 60, 90).contiguous(), IMAGE_F32
+
+    # ---- whole graph -------------------------------------------------------------------
+    def forward(self, img, desvel, quat=None, hidden=None, taps: bool = False, out=None):
+        """module.main_graph with a leading batch.  Returns (vel (B,3), (h, c) each (3,B,128))."""
+        torch = _torch()
+        img, dt = self._image(img)
+        B, dev = img.shape[0], img.device
+        desvel = _dev_f32(desvel).reshape(B)
+        if quat is None:   # refine_inputs default quaternion [1,0,0,0] (QAT/model.py:23-27)
+            quat = torch.zeros((B, 4), dtype=torch.float32, device=dev)
+            quat[:, 0] = 1
+        quat = _dev_f32(quat, (B, 4))
+        if hidden is None:
+            h_in = torch.zeros((3, B, 128), dtype=torch.float32, device=dev)
+            c_in = torch.zeros((3, B, 128), dtype=torch.float32, device=dev)
+        else:
+            h_in, c_in = _dev_f32(hidden[0], (3, B, 128)), _dev_f32(hidden[1], (3, B, 128))
+        if out is None:
+            vel = torch.empty((B, 3), dtype=torch.float32, device=dev)
+            h_out, c_out = torch.empty_like(h_in), torch.empty_like(c_in)
+        else:
+            vel, h_out, c_out = out
+        tp, st = {}, None
+        if taps:
+            mk = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+            tp = dict(tokens=mk(B, 128, self.E), x1=mk(B, 128, self.E), x2=mk(B, 128, self.E), feat=mk(B, 4608),
+                      dec=mk(B, 512))
+            st = C.byref(_FwdTaps(**{k: v.data_ptr() for k, v in tp.items()}))
+        _chk(lib().ita_vitlstm_forward(self._h, img.data_ptr(), dt, desvel.data_ptr(), quat.data_ptr(),
+                                       h_in.data_ptr(), c_in.data_ptr(), vel.data_ptr(), h_out.data_ptr(),
+                                       c_out.data_ptr(), B, st, _stream_ptr()))
+        if taps:
+            return vel, (h_out, c_out), tp
+        return vel, (h_out, c_out)
+
+    # ---- drop-in symbols (host buffers) --------------------------------------------------
+    def bind_dispatch(self, layer: int = 0, dtype: int = DISPATCH_F16):
+        _chk(lib().ita_bind_dispatch(self._h, layer, dtype))
+
+
+class ITAViTLSTM:
+    """Mirror of the reference's ``ITALSTMNetVIT_QAT`` call convention (QAT/model.py:93-132)."""
+
+    def __init__(self, blob: bytes, device: Optional[int] = None, reserve: int = 0):
+        self.engine = Engine(blob, device, reserve)
+
+    def __call__(self, X: Sequence):
+        return self.forward(X)
+
+    def forward(self, X: Sequence):
+        img, desvel = X[0], X[1]
+        quat = X[2] if len(X) > 2 else None
+        hidden = X[3] if len(X) > 3 else None
+        return self.engine.forward(img, desvel, quat, hidden)

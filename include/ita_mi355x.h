@@ -1,0 +1,130 @@
+/*
+ * ita_mi355x.h -- C ABI of libita_mi355x.so, the MI355X (gfx950) replacement for the
+ * reference's ITA custom-dispatch plugin.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and sizes (no torch / HIP types in
+ * the signatures; a stream is passed as `void*` holding a hipStream_t, NULL = default stream)
+ * and -- except the two drop-in symbols whose reference prototype is `void` -- returns an
+ * ita_status.  All file:line citations are relative to the reference repository.
+ *
+ * Boundary being replaced
+ *   samples/inference_udp_FPGA_custom_dispatch/plugin/ITA_dispatch.c:17-27   ITASelfAttention_workgroup
+ *   samples/inference_udp_FPGA_custom_dispatch/plugin/ITA_dispatch.c:31-57   ..._workgroup_expanded
+ *   samples/inference_udp_FPGA_custom_dispatch/plugin/ITA_spec.mlir:6-9,21-33 2 bindings, 0 constants, 1 workgroup
+ *   samples/inference_udp_FPGA_custom_dispatch/main.cpp:171-201               module.main_graph 5-in / 3-out
+ *   tests/export_onnx_for_FPGA.py:71-80                                       I/O names of main_graph
+ */
+#ifndef ITA_MI355X_H_
+#define ITA_MI355X_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ITA_MI355X_ABI_VERSION 1
+
+typedef struct ita_context* ita_handle;
+
+typedef enum ita_status {
+  ITA_OK = 0,
+  ITA_ERR_INVALID_ARG = -1,
+  ITA_ERR_BAD_BLOB = -2,      /* magic / bounds / missing tensor */
+  ITA_ERR_NO_WEIGHTS = -3,    /* compute call before ita_load_weights */
+  ITA_ERR_UNSUPPORTED = -4,   /* dims the kernels are not built for */
+  ITA_ERR_HIP = -5,           /* a HIP runtime call failed; see ita_error_string */
+  ITA_ERR_NO_DEVICE = -6,
+  ITA_ERR_NOT_BOUND = -7      /* drop-in symbol called without ita_bind_dispatch */
+} ita_status;
+
+typedef enum ita_image_dtype { ITA_IMAGE_F32 = 0, ITA_IMAGE_U8 = 1 } ita_image_dtype;
+typedef enum ita_dispatch_dtype { ITA_DISPATCH_F16 = 0, ITA_DISPATCH_F32 = 1 } ita_dispatch_dtype;
+
+/* ---- lifetime --------------------------------------------------------------------------- */
+int ita_abi_version(void);
+/* Creates a context on HIP device `device_ordinal` (-1: the calling thread's current device). */
+int ita_create(ita_handle* out, int device_ordinal);
+int ita_destroy(ita_handle h);
+/* Uploads an "ITAW0001" blob (ita_weights.h) from host memory; replaces any earlier weights.
+ * The reference pre-loads weights into the accelerator out of band
+ * (docs/HOW-TO-run-the-full-project-workflow.md:55); this is that step. */
+int ita_load_weights(ita_handle h, const void* blob, size_t nbytes);
+/* Pre-sizes the internal workspace for batches up to max_batch so that the compute calls below
+ * allocate nothing.  (They grow it on demand otherwise.) */
+int ita_reserve(ita_handle h, int max_batch);
+int ita_get_dims(ita_handle h, int* E, int* S, int* P, int* F, int* H, int* num_layers);
+
+/* ---- errors ------------------------------------------------------------------------------ */
+int ita_last_error(void);                 /* status of the calling thread's last failing call */
+const char* ita_error_string(void);       /* human readable detail for ita_last_error()        */
+
+/* ---- hot path: device pointers, asynchronous on `stream` ---------------------------------- */
+
+/* ITASelfAttention_QAT.forward (models/ITA/QAT/layers.py:101-127): x (B,128,E) f32 -> y (B,128,E)
+ * f32 = dequantised out_proj.  layer < num_layers. */
+int ita_mha_int8(ita_handle h, int layer, const float* x_dev, float* y_dev, int batch, void* stream);
+
+/* As above, also writing the per-stage integer tensors (any pointer may be NULL):
+ * x_q (B,128,E) s8, Q/K/V (B,128,P) s8, logits (B,128,128) s8, probs (B,128,128) u8,
+ * ctx (B,128,P) s8, out_q (B,128,E) s8.  Used by the parity tests
+ * (the reference hooks the same tensors: tests/export_and_validation_W_B.py:25-102). */
+typedef struct ita_mha_taps {
+  int8_t *x_q, *Q, *K, *V, *logits;
+  uint8_t* probs;
+  int8_t *ctx, *out_q;
+} ita_mha_taps;
+int ita_mha_int8_taps(ita_handle h, int layer, const float* x_dev, float* y_dev, int batch,
+                      const ita_mha_taps* taps, void* stream);
+
+/* ITAFeedForward_QAT.forward (models/ITA/QAT/layers.py:61-75). */
+int ita_ffn_int8(ita_handle h, int layer, const float* x_dev, float* y_dev, int batch, void* stream);
+typedef struct ita_ffn_taps { int8_t *x_q, *h, *out_q; } ita_ffn_taps;
+int ita_ffn_int8_taps(ita_handle h, int layer, const float* x_dev, float* y_dev, int batch,
+                      const ita_ffn_taps* taps, void* stream);
+
+/* One encoder layer as the model wires it (QAT/model.py:100-113):
+ * y = LN2(x1 + ffn(x1)),  x1 = LN1(x + mha(x)).  x_dev and y_dev may alias. */
+int ita_encoder_layer(ita_handle h, int layer, const float* x_dev, float* y_dev, int batch, void* stream);
+
+/* OverlapPatchMerging (models/ITA/QAT/layers.py:39-45): image (B,60,90) -> tokens (B,128,E). */
+int ita_tokenizer(ita_handle h, const void* image_dev, int image_dtype, float* tokens_dev, int batch, void* stream);
+
+/* Fusion tail (QAT/model.py:116-121): x (B,128,E) -> (B,9,16,32) flattened, row stride 4608. */
+int ita_fusion_tail(ita_handle h, const float* x_dev, float* feat_dev, int batch, void* stream);
+
+/* module.main_graph with a leading batch (main.cpp:171-201; tests/export_onnx_for_FPGA.py:71-80):
+ *   image (B,1,60,90) f32 or u8 wire frames, additional_data (B,1), quat_data (B,4),
+ *   hidden_in_h / hidden_in_c (3,B,128)  ->  output (B,3), hidden_out_h / hidden_out_c (3,B,128).
+ * hidden_out_* may alias hidden_in_*.  optional float taps (may be NULL): tokens/x1/x2 (B,128,E),
+ * feat (B,4608), dec (B,512). */
+typedef struct ita_forward_taps { float *tokens, *x1, *x2, *feat, *dec; } ita_forward_taps;
+int ita_vitlstm_forward(ita_handle h, const void* image_dev, int image_dtype, const float* additional_data_dev,
+                        const float* quat_data_dev, const float* hidden_in_h_dev, const float* hidden_in_c_dev,
+                        float* output_dev, float* hidden_out_h_dev, float* hidden_out_c_dev, int batch,
+                        const ita_forward_taps* taps, void* stream);
+
+/* ---- drop-in symbols of the reference plugin ---------------------------------------------- */
+
+/* Selects the context/layer the two `void` symbols below run, and the element type of their
+ * host buffers (the reference's C side says uint16 'float16_t', ITA_dispatch.c:7, its MLIR side
+ * says f32, ITA_spec.mlir:30-33; both are supported). */
+int ita_bind_dispatch(ita_handle h, int layer, int dispatch_dtype);
+
+/* Same symbol and prototype as ITA_dispatch.c:17-19.  input/output are HOST buffers of
+ * 1 x 128 x E elements (E = 128 in ITA_spec.mlir); the body is the full int8 attention block
+ * instead of the reference's 16 384-element copy.  Synchronous.  Errors: ita_last_error(). */
+void ITASelfAttention_workgroup(const uint16_t* input, uint16_t* output);
+/* The 10-argument expanded-memref form (ITA_dispatch.c:31-41): base/aligned/offset/size/stride x 2 */
+void ITASelfAttention_workgroup_expanded(const uint16_t* binding0, const uint16_t* binding0_aligned,
+                                         size_t binding0_offset, size_t binding0_size, size_t binding0_stride,
+                                         uint16_t* binding1, uint16_t* binding1_aligned, size_t binding1_offset,
+                                         size_t binding1_size, size_t binding1_stride);
+/* FFN twin for the `abs` marker (models/ITA/export/ITA_ONNX.py:35-38), same buffer convention. */
+void ITAFeedForward_workgroup(const uint16_t* input, uint16_t* output);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ITA_MI355X_H_ */

@@ -1,0 +1,289 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the C ABI,
+against the CPU oracle on the same inputs, and against the committed golden fixtures captured
+from the reference.
+
+Bars: integer / byte tensors bit-exact.  Float stages share the oracle's operation order and are
+compared for equality too, except where the hardware's summation order is not architecturally
+documented (f32 MFMA inside the decoder / LSTM GEMMs): tolerance 1e-5 absolute there, stated
+at the assertion.
+"""
+import ctypes
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden_files
+from drone_oa_iree_vit_accelerator_amd import host, params, synth
+
+pytestmark = pytest.mark.gpu
+
+FIX_ALL = golden_files("*_seed*.npz")
+FIX_VIT = golden_files("vitlstm_*.npz")
+
+
+def _ids(paths):
+    return [p.split("/")[-1][:-4] for p in paths]
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def _engine(d, E, with_float=True, seed=None):
+    fp = synth.float_params(int(d["meta.seed"]) if seed is None else seed, E=E) if with_float else None
+    blob = params.blob_from_record(d, fp, E=E)
+    return host.Engine(blob, device=0), blob, fp
+
+
+def _block_tensors(d):
+    t = params.attention_tensors(d, "attn0.", 0)
+    t.update(params.ffn_tensors(d, "ffn0.", 0))
+    return t
+
+
+@pytest.mark.parametrize("path", FIX_ALL, ids=_ids(FIX_ALL))
+def test_mha_block_bit_exact(torch_cuda, oracle, path):
+    torch = torch_cuda
+    d = params.load_fixture(path)
+    E = int(d["meta.E"])
+    eng, _, _ = _engine(d, E, with_float=(E == 64 and "in0.img_u8" in d))
+    x = d["s0.attn0.x_q.in"]
+    y, taps = eng.mha(torch.from_numpy(x).cuda(), taps=True)
+    torch.cuda.synchronize()
+    oy, otaps = oracle.mha(x, _block_tensors(d), taps=True)
+    for k in ("x_q", "Q", "K", "V", "logits", "probs", "ctx", "out_q"):
+        np.testing.assert_array_equal(taps[k].cpu().numpy(), otaps[k], err_msg=k)
+    np.testing.assert_array_equal(y.cpu().numpy(), oy)
+    # and against the reference's own tensors (fixture): everything but near-tie logit rows
+    np.testing.assert_array_equal(taps["Q"].cpu().numpy(), d["s0.attn0.Q"])
+    np.testing.assert_array_equal(taps["V"].cpu().numpy(), d["s0.attn0.V"])
+    ref_l = d["s0.attn0.probs.in"][:, 0]
+    gl = taps["logits"].cpu().numpy()
+    assert (gl != ref_l).sum() <= 3
+    rows_ok = (gl == ref_l).all(axis=-1)
+    np.testing.assert_array_equal(taps["probs"].cpu().numpy()[rows_ok], d["s0.attn0.probs"][:, 0][rows_ok])
+    np.testing.assert_array_equal(taps["out_q"].cpu().numpy()[rows_ok], d["s0.attn0.out_q"][rows_ok])
+    np.testing.assert_array_equal(y.cpu().numpy()[rows_ok], d["s0.attn0.out_f"][rows_ok])
+    eng.close()
+
+
+@pytest.mark.parametrize("path", FIX_ALL, ids=_ids(FIX_ALL))
+def test_ffn_block_bit_exact(torch_cuda, oracle, path):
+    torch = torch_cuda
+    d = params.load_fixture(path)
+    E = int(d["meta.E"])
+    eng, _, _ = _engine(d, E, with_float=False)
+    x = d["s0.ffn0.x_q.in"]
+    y, taps = eng.ffn(torch.from_numpy(x).cuda(), taps=True)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(taps["x_q"].cpu().numpy(), d["s0.ffn0.x_q"])
+    np.testing.assert_array_equal(taps["h"].cpu().numpy(), d["s0.ffn0.h1_relu"])
+    np.testing.assert_array_equal(taps["out_q"].cpu().numpy(), d["s0.ffn0.out_q"])
+    np.testing.assert_array_equal(y.cpu().numpy(), d["s0.ffn0.out_f"])
+    eng.close()
+
+
+@pytest.mark.parametrize("E", [64, 128])
+def test_blocks_random_batch_and_saturation(torch_cuda, oracle, E):
+    """ragged batch (not a multiple of the grid), saturating / zero / constant rows"""
+    torch = torch_cuda
+    d = params.load_fixture(golden_files(f"blocks_E{E}_seed*.npz")[0])
+    eng, _, _ = _engine(d, E, with_float=False)
+    rs = np.random.RandomState(5)
+    B = 37
+    x = rs.standard_normal((B, 128, E)).astype(np.float32)
+    x[0] = 0.0
+    x[1] = 50.0                      # every code saturates at +127
+    x[2] = -50.0
+    x[3, :, ::2] *= 30.0
+    x[4, 5] = 1e30
+    x[5] = np.float32(0.5) * np.float32(float(d["attn0.quant.scale"]))   # exact rounding ties (x/s = 0.5)
+    x[6] = np.float32(1.5) * np.float32(float(d["attn0.quant.scale"]))
+    t = _block_tensors(d)
+    y, taps = eng.mha(torch.from_numpy(x).cuda(), taps=True)
+    oy, otaps = oracle.mha(x, t, taps=True)
+    for k in otaps:
+        np.testing.assert_array_equal(taps[k].cpu().numpy(), otaps[k], err_msg=k)
+    np.testing.assert_array_equal(y.cpu().numpy(), oy)
+    y2, taps2 = eng.ffn(torch.from_numpy(x).cuda(), taps=True)
+    oy2, otaps2 = oracle.ffn(x, t, taps=True)
+    for k in otaps2:
+        np.testing.assert_array_equal(taps2[k].cpu().numpy(), otaps2[k], err_msg=k)
+    np.testing.assert_array_equal(y2.cpu().numpy(), oy2)
+    eng.close()
+
+
+def test_mha_more_frames_than_workgroups(torch_cuda, oracle):
+    """grid-stride path: B larger than the number of CUs"""
+    torch = torch_cuda
+    d = params.load_fixture(golden_files("blocks_E64_seed2_B1.npz")[0])
+    eng, _, _ = _engine(d, 64, with_float=False)
+    rs = np.random.RandomState(9)
+    B = 2 * 256 + 19
+    x = (1.5 * rs.standard_normal((B, 128, 64))).astype(np.float32)
+    y = eng.mha(torch.from_numpy(x).cuda()).cpu().numpy()
+    oy = oracle.mha(x, _block_tensors(d))
+    np.testing.assert_array_equal(y, oy)
+    eng.close()
+
+
+@pytest.mark.parametrize("path", FIX_VIT, ids=_ids(FIX_VIT))
+def test_float_stages_equal_oracle(torch_cuda, oracle, path):
+    torch = torch_cuda
+    d = params.load_fixture(path)
+    eng, blob, fp = _engine(d, 64)
+    for key, dtype in (("u8", None), ("f32", np.float32)):
+        img = d["in0.img_u8"] if dtype is None else d["in0.img_u8"].astype(np.float32) / np.float32(255.0)
+        tok = eng.tokenizer(torch.from_numpy(img).cuda()).cpu().numpy()
+        img_f = d["in0.img_u8"].astype(np.float32) / np.float32(255.0)
+        otok = oracle.tokenizer(img_f, fp["tokenizer.conv.weight"].reshape(64, 49), fp["tokenizer.conv.bias"],
+                                fp["tokenizer.norm.weight"], fp["tokenizer.norm.bias"])
+        np.testing.assert_array_equal(tok, otok, err_msg=key)
+        np.testing.assert_allclose(tok, d["s0.tok.out"], atol=2e-5, rtol=0)
+    x2 = d["s0.x2"]
+    feat = eng.fusion_tail(torch.from_numpy(x2).cuda()).cpu().numpy()
+    ofeat = oracle.tail(x2, fp["down_sample.weight"], fp["down_sample.bias"])
+    np.testing.assert_array_equal(feat, ofeat)
+    np.testing.assert_allclose(feat.reshape(-1, 9, 16, 32), d["s0.tail.conv"], atol=2e-5, rtol=0)
+    # one encoder layer with the fused residual + LayerNorm epilogues
+    x = d["s0.tok.out"]
+    y = eng.encoder_layer(torch.from_numpy(x).cuda()).cpu().numpy()
+    t = _block_tensors(d)
+    x1 = oracle.add_ln(x, oracle.mha(x, t), fp["norms1.0.weight"], fp["norms1.0.bias"])
+    ox2 = oracle.add_ln(x1, oracle.ffn(x1, t), fp["norms2.0.weight"], fp["norms2.0.bias"])
+    np.testing.assert_array_equal(y, ox2)
+    eng.close()
+
+
+@pytest.mark.parametrize("path", FIX_VIT, ids=_ids(FIX_VIT))
+def test_full_forward_two_steps(torch_cuda, oracle, path):
+    torch = torch_cuda
+    d = params.load_fixture(path)
+    eng, blob, fp = _engine(d, 64)
+    cu = lambda a: torch.from_numpy(a).cuda()
+    vel0, (h0, c0), tp = eng.forward(cu(d["in0.img_u8"]), cu(d["in0.desvel"]), cu(d["in0.quat"]), taps=True)
+    ovel0, oh0, oc0, otp = oracle.forward(blob, d["in0.img_u8"], d["in0.desvel"], d["in0.quat"], taps=True)
+    for k in ("tokens", "x1", "x2", "feat"):
+        np.testing.assert_array_equal(tp[k].cpu().numpy(), otp[k], err_msg=k)
+    # decoder / LSTM run on f32 MFMA (documented as a k-ordered fmaf chain; tolerance 1e-5 in case
+    # the within-instruction order differs from ascending k)
+    np.testing.assert_allclose(tp["dec"].cpu().numpy(), otp["dec"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(vel0.cpu().numpy(), ovel0, atol=1e-5, rtol=0)
+    np.testing.assert_allclose(h0.cpu().numpy(), oh0, atol=1e-5, rtol=0)
+    np.testing.assert_allclose(c0.cpu().numpy(), oc0, atol=1e-5, rtol=0)
+    # second time step, state carried on the device like the reference host carries it
+    vel1, (h1, c1) = eng.forward(cu(d["in1.img_u8"]), cu(d["in1.desvel"]), cu(d["in1.quat"]), (h0, c0))
+    ovel1, oh1, oc1 = oracle.forward(blob, d["in1.img_u8"], d["in1.desvel"], d["in1.quat"], oh0, oc0)
+    np.testing.assert_allclose(vel1.cpu().numpy(), ovel1, atol=2e-5, rtol=0)
+    np.testing.assert_allclose(h1.cpu().numpy(), oh1, atol=2e-5, rtol=0)
+    # against the reference's own outputs (fixture): int8 flips behind float LayerNorms allowed
+    np.testing.assert_allclose(vel0.cpu().numpy(), d["s0.vel"], atol=5e-4, rtol=0)
+    np.testing.assert_allclose(vel1.cpu().numpy(), d["s1.vel"], atol=5e-4, rtol=0)
+    np.testing.assert_allclose(c1.cpu().numpy(), d["s1.c"], atol=5e-4, rtol=0)
+    # reference call convention: default quaternion, no hidden state
+    model = host.ITAViTLSTM(blob, device=0)
+    v, (hh, cc) = model([cu(d["in0.img_u8"]), cu(d["in0.desvel"])])
+    q = np.zeros((2, 4), np.float32); q[:, 0] = 1
+    ov, _, _ = oracle.forward(blob, d["in0.img_u8"], d["in0.desvel"], q)
+    np.testing.assert_allclose(v.cpu().numpy(), ov, atol=1e-5, rtol=0)
+    eng.close()
+
+
+def test_decoder_lstm_exactness_report(torch_cuda, oracle):
+    """Not a gate: records whether the f32-MFMA GEMMs reproduce the oracle's fmaf chain bit for bit."""
+    torch = torch_cuda
+    d = params.load_fixture(FIX_VIT[0])
+    eng, blob, fp = _engine(d, 64)
+    cu = lambda a: torch.from_numpy(a).cuda()
+    vel, (h, c), tp = eng.forward(cu(d["in0.img_u8"]), cu(d["in0.desvel"]), cu(d["in0.quat"]), taps=True)
+    ovel, oh, oc, otp = oracle.forward(blob, d["in0.img_u8"], d["in0.desvel"], d["in0.quat"], taps=True)
+    nd = int((tp["dec"].cpu().numpy() != otp["dec"]).sum())
+    nh = int((h.cpu().numpy() != oh).sum())
+    nv = int((vel.cpu().numpy() != ovel).sum())
+    print(f"\n[exactness] decoder mismatches {nd}/{otp['dec'].size}, h {nh}/{oh.size}, vel {nv}/{ovel.size}; "
+          f"max |dec diff| {np.abs(tp['dec'].cpu().numpy() - otp['dec']).max():.3e}")
+    eng.close()
+
+
+def test_full_size_properties(torch_cuda, oracle):
+    """BASELINE config 4 size (B = 1024): determinism, batch-composition independence, and a
+    sampled oracle check (the oracle needs ~25 ms per frame)."""
+    torch = torch_cuda
+    d = params.load_fixture(FIX_VIT[0])
+    eng, blob, fp = _engine(d, 64)
+    B = 1024
+    fr = synth.frames(77, B)
+    cu = lambda a: torch.from_numpy(a).cuda()
+    img, dv, qt = cu(fr["img_u8"]), cu(fr["desvel"]), cu(fr["quat"])
+    h = torch.from_numpy(np.random.RandomState(3).standard_normal((3, B, 128)).astype(np.float32) * 0.1).cuda()
+    c = torch.from_numpy(np.random.RandomState(4).standard_normal((3, B, 128)).astype(np.float32) * 0.1).cuda()
+    v1, (h1, c1) = eng.forward(img, dv, qt, (h, c))
+    v2, (h2, c2) = eng.forward(img, dv, qt, (h, c))
+    assert torch.equal(v1, v2) and torch.equal(h1, h2) and torch.equal(c1, c2)
+    # a frame's result does not depend on what else is in the batch or where it sits
+    idx = torch.tensor([1023, 0, 511, 300, 7], device="cuda")
+    vs, (hs, cs) = eng.forward(img[idx], dv[idx], qt[idx], (h[:, idx].contiguous(), c[:, idx].contiguous()))
+    assert torch.equal(vs, v1[idx]) and torch.equal(hs, h1[:, idx]) and torch.equal(cs, c1[:, idx])
+    sel = [0, 255, 256, 777, 1023]
+    ov, oh, oc = oracle.forward(blob, fr["img_u8"][sel], fr["desvel"][sel], fr["quat"][sel],
+                                h.cpu().numpy()[:, sel], c.cpu().numpy()[:, sel])
+    np.testing.assert_allclose(v1.cpu().numpy()[sel], ov, atol=1e-5, rtol=0)
+    np.testing.assert_allclose(c1.cpu().numpy()[:, sel], oc, atol=1e-5, rtol=0)
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype", ["f16", "f32"])
+def test_dropin_symbol_host_buffers(torch_cuda, oracle, dtype):
+    """ITASelfAttention_workgroup(in, out) with the reference's prototype: host buffers of
+    1 x 128 x 128 elements (ITA_spec.mlir:30-33), full attention block instead of a copy."""
+    d = params.load_fixture(golden_files("blocks_E128_seed0_B1.npz")[0])
+    eng, _, _ = _engine(d, 128, with_float=False)
+    x = d["s0.attn0.x_q.in"][0]
+    lib = host.lib()
+    if dtype == "f16":
+        eng.bind_dispatch(0, host.DISPATCH_F16)
+        xin = x.astype(np.float16)
+        out = np.empty_like(xin)
+        want = oracle.mha(xin.astype(np.float32)[None], _block_tensors(d))[0].astype(np.float16)
+    else:
+        eng.bind_dispatch(0, host.DISPATCH_F32)
+        xin = x.copy()
+        out = np.empty_like(xin)
+        want = oracle.mha(xin[None], _block_tensors(d))[0]
+    lib.ITASelfAttention_workgroup(xin.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+    assert lib.ita_last_error() == 0, lib.ita_error_string()
+    np.testing.assert_array_equal(out, want)
+    out2 = np.empty_like(xin)
+    lib.ITASelfAttention_workgroup_expanded(None, xin.ctypes.data_as(ctypes.c_void_p), 0, xin.size, 1, None,
+                                            out2.ctypes.data_as(ctypes.c_void_p), 0, out2.size, 1)
+    np.testing.assert_array_equal(out2, want)
+    fo = np.empty_like(xin)
+    lib.ITAFeedForward_workgroup(xin.ctypes.data_as(ctypes.c_void_p), fo.ctypes.data_as(ctypes.c_void_p))
+    wf = oracle.ffn(xin.astype(np.float32)[None], _block_tensors(d))[0].astype(xin.dtype)
+    np.testing.assert_array_equal(fo, wf)
+    eng.close()
+
+
+def test_error_codes_on_gpu(torch_cuda):
+    lib = host.lib()
+    h = ctypes.c_void_p()
+    assert lib.ita_create(ctypes.byref(h), 0) == 0
+    x = torch_cuda.zeros((1, 128, 64), device="cuda")
+    assert lib.ita_mha_int8(h, 0, x.data_ptr(), x.data_ptr(), 1, None) == -3          # no weights
+    bad = ctypes.create_string_buffer(b"NOTABLOB" + b"\0" * 128)
+    assert lib.ita_load_weights(h, bad, 136) == -2
+    d = params.load_fixture(golden_files("blocks_E64_seed2_B1.npz")[0])
+    blob = params.blob_from_record(d, None, E=64)
+    buf = ctypes.create_string_buffer(blob, len(blob))
+    assert lib.ita_load_weights(h, buf, len(blob)) == 0
+    assert lib.ita_mha_int8(h, 3, x.data_ptr(), x.data_ptr(), 1, None) == -1          # layer out of range
+    assert lib.ita_mha_int8(h, 0, x.data_ptr(), x.data_ptr(), 0, None) == -1          # empty batch
+    # a block-only blob cannot run the whole graph
+    assert lib.ita_vitlstm_forward(h, x.data_ptr(), 0, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(),
+                                   x.data_ptr(), x.data_ptr(), x.data_ptr(), 1, None, None) == -2
+    assert lib.ita_destroy(h) == 0
