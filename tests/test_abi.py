@@ -45,7 +45,9 @@ def test_error_paths_without_gpu(so):
 def test_code_object_targets_gfx950(so):
     import tempfile
     with tempfile.TemporaryDirectory() as td:      # --offloading drops the extracted code objects in cwd
-        out = os.popen(f"cd {td} && /opt/rocm/lib/llvm/bin/llvm-objdump --offloading {so} 2>/dev/null").read()
+        import shutil
+        cp = shutil.copy(so, td)
+        out = os.popen(f"cd {td} && /opt/rocm/lib/llvm/bin/llvm-objdump --offloading {cp} 2>/dev/null").read()
     if not out:
         pytest.skip("llvm-objdump unavailable")
     assert "gfx950" in out
