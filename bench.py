@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the ITAViTLSTM int8 forward on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One "step" = one pass of module.main_graph (tokenizer -> int8 MHA -> int8 FFN -> fusion tail ->
+decoder -> 3-layer LSTM -> fc) over one batch of synthetic 60x90 depth frames per GPU
+(BASELINE config 4: 1024 frames), inputs resident in HBM, LSTM state carried from step to step,
+plus -- for N > 1 -- the RCCL all-gather of the (frames, 3) velocities.  Weak scaling: every GPU
+always processes `--frames-per-gpu` independent streams.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      dominant kernel: algorithmic ops per launch / its HIP-event time measured in the
+                timed region, against the MI355X peak for its arithmetic (guide: int8 MFMA
+                5.0 POP/s dense, f32 157.3 TFLOP/s)
+  cpu_baseline  the CPU oracle (oracle/ita_oracle.c, a scalar port) timed on one host core on a
+                bounded sample of the same workload (N = 1 only)
+"""
+import argparse
+import glob
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+
+# algorithmic work per frame (BASELINE.md section 2 / SURVEY.md section 8(d)); E=64, S=128, P=192, F=256
+STAGE_WORK = {   # stage: (ops per frame, bound, peak in Tera-op/s, arithmetic)
+    "tokenizer": (2 * 4.23e6, "mfma", 157.3, "f32"),
+    "mha": (2 * 12.58e6, "mfma", 5000.0, "int8"),
+    "ffn": (2 * 4.19e6, "mfma", 5000.0, "int8"),
+    "tail": (2 * 3.32e6, "mfma", 157.3, "f32"),
+    "decoder": (2 * 2.36e6, "mfma", 157.3, "f32"),
+    "lstm_fc": (2 * 0.59e6, "mfma", 157.3, "f32"),
+}
+
+
+def cpu_baseline(blob, B_target_s=12.0):
+    from drone_oa_iree_vit_accelerator_amd import synth
+    from oracle import oracle
+    fr = synth.frames(1234, 64)
+    t0 = time.perf_counter()
+    oracle.forward(blob, fr["img_u8"][:4], fr["desvel"][:4], fr["quat"][:4])
+    per = (time.perf_counter() - t0) / 4
+    n = int(max(8, min(64, B_target_s / max(per, 1e-6))))
+    reps = max(1, int(round(B_target_s / (per * n))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        oracle.forward(blob, fr["img_u8"][:n], fr["desvel"][:n], fr["quat"][:n])
+    dt = time.perf_counter() - t0
+    return {"value": round(n * reps / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} x {n} frames of the same synthetic workload through oracle/ita_oracle.c "
+                      f"(scalar C, 1 thread, {dt:.1f} s)",
+            "host_cores_available": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--frames-per-gpu", type=int, default=1024)
+    ap.add_argument("--image-dtype", choices=["f32", "u8"], default="f32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from drone_oa_iree_vit_accelerator_amd import dist as itadist
+    from drone_oa_iree_vit_accelerator_amd import host, params, synth
+
+    rank, local_rank, world = itadist.env_world()
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    itadist.init("nccl", local_rank)
+
+    B, K, W = a.frames_per_gpu, a.steps, a.warmup
+    fx = params.load_fixture(os.path.join(REPO, "tests", "golden", "vitlstm_E64_seed0_B2.npz"))
+    blob = params.blob_from_record(fx, synth.float_params(0, E=64), E=64)     # weights: seed 0 synthetic-QAT
+    eng = host.Engine(blob, device=local_rank, reserve=B)
+    fr = synth.frames(1234 + rank, B)
+    if a.image_dtype == "u8":
+        img = torch.from_numpy(fr["img_u8"]).to(dev)
+    else:
+        img = (torch.from_numpy(fr["img_u8"]).to(dev).float() / 255.0).contiguous()
+    dv, qt = torch.from_numpy(fr["desvel"]).to(dev), torch.from_numpy(fr["quat"]).to(dev)
+    state = [(torch.zeros((3, B, 128), device=dev), torch.zeros((3, B, 128), device=dev)) for _ in range(2)]
+    vel = torch.empty((B, 3), device=dev)
+    gather = itadist.VelocityGather(B, world, dev)
+
+    def step(i):
+        src, dst = state[i & 1], state[(i + 1) & 1]
+        eng.forward(img, dv, qt, src, out=(vel, dst[0], dst[1]))
+        if world > 1:
+            gather.start(vel)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(W):
+        step(i)
+    gather.finish()
+    fence()
+    eng.profile_begin(min(K, 512))
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(W + i)
+    gather.finish()
+    fence()
+    elapsed = time.perf_counter() - t0
+    stage_ms, nprof = eng.profile_end()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    out = None
+    if rank == 0:
+        per = {k: v / max(nprof, 1) for k, v in stage_ms.items()}
+        dom = max(per, key=per.get)
+        ops, bound, peak, arith = STAGE_WORK[dom]
+        achieved = ops * B / (per[dom] * 1e-3) / 1e12
+        roof = {"kernel": dom, "bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 5), "traffic": None, "arithmetic": arith,
+                "ops_per_launch": ops * B, "avg_launch_ms": round(per[dom], 5), "launches_timed": nprof}
+        stages = {}
+        for k, ms in per.items():
+            o, _, pk, ar = STAGE_WORK[k]
+            ach = o * B / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            stages[k] = {"ms": round(ms, 5), "achieved_Tops": round(ach, 3), "peak_Tops": pk, "frac": round(ach / pk, 5),
+                         "arithmetic": ar}
+        out = {
+            "metric": "frames/s on ITAViTLSTM int8, 60x90 depth input",
+            "value": round(world * B * K / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(elapsed / K * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int8+f32", "data": "synthetic",
+            "config": {"workload": "ITAViTLSTM int8 end-to-end forward (BASELINE config 4): 1024 synthetic 60x90 "
+                                   "depth frames per GPU per step, LSTM state carried, velocity all-gather",
+                       "frames_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "image_dtype": a.image_dtype, "weights": "seed-0 synthetic QAT (tests/golden)"},
+            "roofline": roof, "stages": stages,
+        }
+        if not a.no_latency:      # p50 single-frame latency, host enqueue -> result ready
+            e1 = host.Engine(blob, device=local_rank, reserve=1)
+            i1, d1, q1 = img[:1].contiguous(), dv[:1].contiguous(), qt[:1].contiguous()
+            st = (torch.zeros((3, 1, 128), device=dev), torch.zeros((3, 1, 128), device=dev))
+            lat = []
+            for it in range(250):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                v1, st = e1.forward(i1, d1, q1, st)
+                torch.cuda.synchronize()
+                lat.append(time.perf_counter() - t1)
+            out["p50_latency_ms_b1"] = round(float(np.median(lat[50:])) * 1e3, 4)
+            e1.close()
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(blob)
+        else:
+            out["cpu_baseline"] = None
+    fence()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

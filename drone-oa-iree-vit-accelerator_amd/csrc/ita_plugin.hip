@@ -64,6 +64,10 @@ struct ita_context {
   int cap = 0;
   float *bufA = nullptr, *bufB = nullptr, *cat0 = nullptr, *cat1 = nullptr, *cat2 = nullptr, *gates = nullptr,
         *feat = nullptr;
+  // per-stage profiling (ita_profile_begin / _end)
+  bool prof = false;
+  int prof_max = 0, prof_n = 0;
+  std::vector<hipEvent_t> prof_ev;   // per recorded forward: 1 + 1 + 2*L + 3 events
   // staging for the host-buffer drop-in symbols
   float *dsp_in = nullptr, *dsp_out = nullptr;
   std::vector<float> dsp_host;
@@ -274,6 +278,7 @@ int ita_destroy(ita_handle h) {
   (void)hipSetDevice(h->device);
   free_weights(h);
   free_workspace(h);
+  for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
   if (h->dsp_in) (void)hipFree(h->dsp_in);
   if (h->dsp_out) (void)hipFree(h->dsp_out);
   delete h;
@@ -451,20 +456,30 @@ int ita_vitlstm_forward(ita_handle h, const void* image, int image_dtype, const 
   hipStream_t s = (hipStream_t)stream;
   const int B = batch;
   const size_t tokb = sizeof(float) * (size_t)B * 128 * h->hdr.E;
+  const int ev_per_fwd = 5 + 2 * h->hdr.num_layers;
+  hipEvent_t* ev = (h->prof && h->prof_n < h->prof_max) ? &h->prof_ev[(size_t)h->prof_n * ev_per_fwd] : nullptr;
+  int evi = 0;
+#define MARK() do { if (ev) HIPCHK(hipEventRecord(ev[evi++], s)); } while (0)
+  MARK();
   if ((rc = launch_tokenizer(h, image, image_dtype, h->bufA, B, s))) return rc;
+  MARK();
   if (taps && taps->tokens) HIPCHK(hipMemcpyAsync(taps->tokens, h->bufA, tokb, hipMemcpyDeviceToDevice, s));
   for (int l = 0; l < h->hdr.num_layers; ++l) {
     if ((rc = launch_mha(h, l, h->bufA, h->bufB, B, true, nullptr, s))) return rc;
+    MARK();
     if (taps && taps->x1 && l == h->hdr.num_layers - 1)
       HIPCHK(hipMemcpyAsync(taps->x1, h->bufB, tokb, hipMemcpyDeviceToDevice, s));
     if ((rc = launch_ffn(h, l, h->bufB, h->bufA, B, true, nullptr, s))) return rc;
+    MARK();
   }
   if (taps && taps->x2) HIPCHK(hipMemcpyAsync(taps->x2, h->bufA, tokb, hipMemcpyDeviceToDevice, s));
   if ((rc = launch_tail(h, h->bufA, h->feat, 4608, B, s))) return rc;
+  MARK();
   if (taps && taps->feat)
     HIPCHK(hipMemcpyAsync(taps->feat, h->feat, sizeof(float) * (size_t)B * 4608, hipMemcpyDeviceToDevice, s));
   // decoder writes straight into the LSTM layer-0 concat buffer (columns 0..511)
   if ((rc = launch_gemm(h->feat, 4608, h->dec_w, 4608, h->dec_b, h->cat0, K0P, B, 512, 4608, s))) return rc;
+  MARK();
   if (taps && taps->dec)
     HIPCHK(hipMemcpy2DAsync(taps->dec, 512 * sizeof(float), h->cat0, K0P * sizeof(float), 512 * sizeof(float), B,
                             hipMemcpyDeviceToDevice, s));
@@ -485,6 +500,55 @@ int ita_vitlstm_forward(ita_handle h, const void* image, int image_dtype, const 
   hipLaunchKernelGGL(ita_fc_kernel, dim3((B * 3 + 63) / 64), dim3(64), 0, s, h_out + (size_t)2 * B * 128, h->fc_w,
                      h->fc_b, vel, B);
   HIPCHK(hipGetLastError());
+  MARK();
+#undef MARK
+  if (ev) ++h->prof_n;
+  return ITA_OK;
+}
+
+int ita_profile_begin(ita_handle h, int max_forwards) {
+  int rc = check(h, 1);
+  if (rc) return rc;
+  if (max_forwards <= 0 || max_forwards > 4096) return fail(ITA_ERR_INVALID_ARG, "max_forwards out of range");
+  const size_t need = (size_t)max_forwards * (5 + 2 * h->hdr.num_layers);
+  while (h->prof_ev.size() < need) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    h->prof_ev.push_back(e);
+  }
+  h->prof = true;
+  h->prof_max = max_forwards;
+  h->prof_n = 0;
+  return ITA_OK;
+}
+
+int ita_profile_end(ita_handle h, double* stage_ms, int* n_forwards) {
+  if (!h || !stage_ms || !n_forwards) return fail(ITA_ERR_INVALID_ARG, "null argument");
+  HIPCHK(hipSetDevice(h->device));
+  h->prof = false;
+  const int L = h->hdr.num_layers, per = 5 + 2 * L;
+  for (int i = 0; i < ITA_NUM_STAGES; ++i) stage_ms[i] = 0.0;
+  for (int f = 0; f < h->prof_n; ++f) {
+    hipEvent_t* ev = &h->prof_ev[(size_t)f * per];
+    HIPCHK(hipEventSynchronize(ev[per - 1]));
+    auto dt = [&](int a, int b, double* acc) -> int {
+      float ms = 0.0f;
+      HIPCHK(hipEventElapsedTime(&ms, ev[a], ev[b]));
+      *acc += ms;
+      return ITA_OK;
+    };
+    int rc;
+    if ((rc = dt(0, 1, &stage_ms[0]))) return rc;
+    for (int l = 0; l < L; ++l) {
+      if ((rc = dt(1 + 2 * l, 2 + 2 * l, &stage_ms[1]))) return rc;
+      if ((rc = dt(2 + 2 * l, 3 + 2 * l, &stage_ms[2]))) return rc;
+    }
+    if ((rc = dt(1 + 2 * L, 2 + 2 * L, &stage_ms[3]))) return rc;
+    if ((rc = dt(2 + 2 * L, 3 + 2 * L, &stage_ms[4]))) return rc;
+    if ((rc = dt(3 + 2 * L, 4 + 2 * L, &stage_ms[5]))) return rc;
+  }
+  *n_forwards = h->prof_n;
+  h->prof_n = 0;
   return ITA_OK;
 }
 

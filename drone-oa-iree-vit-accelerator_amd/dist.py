@@ -1,0 +1,90 @@
+"""Multi-GPU layer: one process per GPU, frames sharded as independent streams.
+
+The reference has no distributed code at all (IREE reports `Collectives: 0`,
+output/compilation_info.txt:11); the only exchange this engine adds is the one the task
+names: a gather of the (frames, 3) velocity outputs.  Each stream's LSTM state (h, c) stays
+on the GPU that owns the stream and is never communicated.  The message is 12 bytes per frame
+(12 KiB per rank at 1024 frames) -- latency-bound on xGMI, so it is one all-gather per step
+(a single hop on the fully connected fabric), issued asynchronously so that it overlaps the
+next step's kernels.
+
+Works with backend "nccl" (= RCCL on ROCm) on GPU tensors and "gloo" on CPU tensors (tests).
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+
+def env_world() -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torch.distributed.run environment."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of `total` streams for `rank`; sizes differ by at most one."""
+    if not (0 <= rank < world) or total < 0:
+        raise ValueError("bad rank/world/total")
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init(backend: Optional[str] = None, device_index: Optional[int] = None):
+    """Initialises torch.distributed from the environment when WORLD_SIZE > 1."""
+    import torch
+    import torch.distributed as dist
+    rank, local_rank, world = env_world()
+    if world == 1 or dist.is_initialized():
+        return rank, local_rank, world
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    kw = {}
+    if backend == "nccl":
+        kw["device_id"] = torch.device("cuda", local_rank if device_index is None else device_index)
+    dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, local_rank, world
+
+
+class VelocityGather:
+    """Double-buffered asynchronous all-gather of per-rank (frames, 3) velocity tensors.
+
+    All ranks must hold the same number of frames (bench.py: fixed frames per GPU).  `start`
+    issues the collective for this step and returns immediately; `result` waits for it."""
+
+    def __init__(self, frames_per_rank: int, world: int, device, dtype=None):
+        import torch
+        self.world = world
+        self.n = frames_per_rank
+        dtype = dtype or torch.float32
+        self.bufs = [torch.empty((world * frames_per_rank, 3), dtype=dtype, device=device) for _ in range(2)]
+        self.handles = [None, None]
+        self.i = 0
+
+    def start(self, vel):
+        import torch.distributed as dist
+        i = self.i
+        if self.handles[i] is not None:       # buffer about to be reused: its collective must be done
+            self.handles[i].wait()
+        if self.world == 1:
+            self.bufs[i].copy_(vel)
+            self.handles[i] = None
+        else:
+            self.handles[i] = dist.all_gather_into_tensor(self.bufs[i], vel.contiguous(), async_op=True)
+        self.i ^= 1
+        return i
+
+    def result(self, i: int):
+        if self.handles[i] is not None:
+            self.handles[i].wait()
+            self.handles[i] = None
+        return self.bufs[i]
+
+    def finish(self):
+        for i in (0, 1):
+            if self.handles[i] is not None:
+                self.handles[i].wait()
+                self.handles[i] = None

@@ -31,6 +31,7 @@ EXPORTED_SYMBOLS = (
     "ita_abi_version", "ita_create", "ita_destroy", "ita_load_weights", "ita_reserve", "ita_get_dims",
     "ita_last_error", "ita_error_string", "ita_mha_int8", "ita_mha_int8_taps", "ita_ffn_int8", "ita_ffn_int8_taps",
     "ita_encoder_layer", "ita_tokenizer", "ita_fusion_tail", "ita_vitlstm_forward", "ita_bind_dispatch",
+    "ita_profile_begin", "ita_profile_end",
     "ITASelfAttention_workgroup", "ITASelfAttention_workgroup_expanded", "ITAFeedForward_workgroup",
 )
 
@@ -93,6 +94,8 @@ def lib():
         L.ita_fusion_tail.argtypes = [vp, vp, vp, i, vp]
         L.ita_vitlstm_forward.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, vp, vp, i, C.POINTER(_FwdTaps), vp]
         L.ita_bind_dispatch.argtypes = [vp, i, i]
+        L.ita_profile_begin.argtypes = [vp, i]
+        L.ita_profile_end.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i)]
         L.ITASelfAttention_workgroup.argtypes = [vp, vp]
         L.ITASelfAttention_workgroup.restype = None
         L.ITAFeedForward_workgroup.argtypes = [vp, vp]
@@ -258,6 +261,19 @@ class Engine:
         if taps:
             return vel, (h_out, c_out), tp
         return vel, (h_out, c_out)
+
+    # ---- per-stage device timing ---------------------------------------------------------
+    STAGES = ("tokenizer", "mha", "ffn", "tail", "decoder", "lstm_fc")
+
+    def profile_begin(self, max_forwards: int):
+        _chk(lib().ita_profile_begin(self._h, max_forwards))
+
+    def profile_end(self):
+        """-> ({stage: summed ms}, forwards covered)"""
+        ms = (C.c_double * 6)()
+        n = C.c_int()
+        _chk(lib().ita_profile_end(self._h, ms, C.byref(n)))
+        return dict(zip(self.STAGES, list(ms))), n.value
 
     # ---- drop-in symbols (host buffers) --------------------------------------------------
     def bind_dispatch(self, layer: int = 0, dtype: int = DISPATCH_F16):

@@ -105,6 +105,16 @@ int ita_vitlstm_forward(ita_handle h, const void* image_dev, int image_dtype, co
                         float* output_dev, float* hidden_out_h_dev, float* hidden_out_c_dev, int batch,
                         const ita_forward_taps* taps, void* stream);
 
+/* ---- per-stage timing (bench.py's roofline leg) -------------------------------------------- */
+/* Between ita_profile_begin and ita_profile_end every ita_vitlstm_forward call records HIP
+ * events on ITS OWN stream around each stage; ita_profile_end synchronises them and returns
+ * the summed device time per stage in milliseconds and the number of forwards covered.
+ * Stages: 0 tokenizer, 1 int8 MHA (+LN1), 2 int8 FFN (+LN2), 3 fusion tail, 4 decoder GEMM,
+ * 5 LSTM + fc.  At most max_forwards calls are recorded (later ones run unprofiled). */
+#define ITA_NUM_STAGES 6
+int ita_profile_begin(ita_handle h, int max_forwards);
+int ita_profile_end(ita_handle h, double* stage_ms, int* n_forwards);
+
 /* ---- drop-in symbols of the reference plugin ---------------------------------------------- */
 
 /* Selects the context/layer the two `void` symbols below run, and the element type of their
