@@ -44,6 +44,9 @@ struct ItaFfnArgs {
   int B;
   int fuse_ln;
   int8_t *t_xq, *t_h, *t_out;
+  // optional second form of the output: f16 hi/lo planes [B][128*E] for the split-precision tail
+  // GEMM (ita_f16x3_kernels.h); y may then be null
+  _Float16 *y_hi, *y_lo;
 };
 
 template <int E>
@@ -97,7 +100,9 @@ __device__ __forceinline__ void quantize_tokens(const float* __restrict__ xrow, 
 template <int E>
 __device__ __forceinline__ void finish_tokens(const char* lds_outq, float so, const float (&xr)[E / 4], int token,
                                               int qtr, bool fuse_ln, const float* __restrict__ ln_w,
-                                              const float* __restrict__ ln_b, float* __restrict__ yrow) {
+                                              const float* __restrict__ ln_b, float* __restrict__ yrow,
+                                              _Float16* __restrict__ hi_row = nullptr,
+                                              _Float16* __restrict__ lo_row = nullptr) {
   constexpr int EC = E / 4;
   float r[EC];
 #pragma unroll
@@ -114,10 +119,27 @@ __device__ __forceinline__ void finish_tokens(const char* lds_outq, float so, co
     for (int i = 0; i < EC; ++i) r[i] = xr[i] + r[i];
     layernorm_lanes<E, 4>(r, ln_w, ln_b, qtr * EC);
   }
+  if (yrow) {
 #pragma unroll
-  for (int i = 0; i < EC; i += 4) {
-    f32x4 v = {r[i], r[i + 1], r[i + 2], r[i + 3]};
-    *(f32x4*)(yrow + i) = v;
+    for (int i = 0; i < EC; i += 4) {
+      f32x4 v = {r[i], r[i + 1], r[i + 2], r[i + 3]};
+      *(f32x4*)(yrow + i) = v;
+    }
+  }
+  if (hi_row) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+    for (int i = 0; i < EC; i += 8) {
+      h8 vh, vl;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const _Float16 hh = (_Float16)r[i + j];
+        vh[j] = hh;
+        vl[j] = (_Float16)(r[i + j] - (float)hh);
+      }
+      *(h8*)(hi_row + i) = vh;
+      *(h8*)(lo_row + i) = vl;
+    }
   }
 }
 
@@ -352,7 +374,8 @@ __global__ __launch_bounds__(512) void ita_ffn_kernel(const ItaFfnArgs a) {
                            a.t_out ? a.t_out + (size_t)b * S * E : nullptr, E);
     }
     __syncthreads();
-    finish_tokens<E>(lds + L::OUTQ, a.s2, xr, token, qtr, a.fuse_ln != 0, a.ln_w, a.ln_b,
-                     a.y + ((size_t)b * S + token) * E + qtr * EC);
+    const size_t o = ((size_t)b * S + token) * E + qtr * EC;
+    finish_tokens<E>(lds + L::OUTQ, a.s2, xr, token, qtr, a.fuse_ln != 0, a.ln_w, a.ln_b, a.y ? a.y + o : nullptr,
+                     a.y_hi ? a.y_hi + o : nullptr, a.y_lo ? a.y_lo + o : nullptr);
   }
 }

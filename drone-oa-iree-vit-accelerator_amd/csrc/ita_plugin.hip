@@ -14,6 +14,7 @@
 
 #include "../../include/ita_mi355x.h"
 #include "../../include/ita_weights.h"
+#include "ita_f16x3_kernels.h"
 #include "ita_f32_kernels.h"
 #include "ita_int8_kernels.h"
 
@@ -34,7 +35,10 @@ int fail(int code, const std::string& msg) {
       return fail(ITA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                \
   } while (0)
 
-constexpr int K0P = 672;   // LSTM layer-0 concat width 517 + 128 = 645, zero padded to a multiple of 32
+constexpr int K0P = 672;    // exact-f32 path: LSTM layer-0 concat width 517 + 128 = 645, padded to a multiple of 32
+constexpr int K0F = 704;    // f16x3 path: padded to a multiple of 64
+constexpr int KFOLD = 8192; // 128 tokens x 64 channels feeding the folded tail+decoder matrix
+constexpr int NSPLIT = 8;   // split-K of the folded GEMM (1024 x 512 x 8192 -> 256 workgroups)
 
 struct Layer {
   const int8_t *wq, *wk, *wv, *wo, *w1, *w2;
@@ -60,6 +64,18 @@ struct ita_context {
   float* tail_wT = nullptr;
   float* wcat[3] = {nullptr, nullptr, nullptr};
   float* bsum[3] = {nullptr, nullptr, nullptr};
+  // split-precision (f16 hi/lo) tail: folded tail+decoder matrix and LSTM weights, pre-scaled
+  int tail_mode = 1;                       // 1: folded f16x3 GEMMs (default), 0: exact f32 kernels
+  bool folded = false;
+  _Float16 *fold_hi = nullptr, *fold_lo = nullptr;   // [512][8192]
+  float* fold_bias = nullptr;                        // [512] = dec(tail(0))
+  float fold_inv_scale = 1.0f;
+  _Float16 *lw_hi[3] = {nullptr, nullptr, nullptr}, *lw_lo[3] = {nullptr, nullptr, nullptr};   // [512][K0F | 256]
+  float lw_inv_scale[3] = {1.0f, 1.0f, 1.0f};
+  // workspace of the f16x3 path
+  _Float16 *x2_hi = nullptr, *x2_lo = nullptr, *c0_hi = nullptr, *c0_lo = nullptr, *c1_hi = nullptr, *c1_lo = nullptr,
+           *c2_hi = nullptr, *c2_lo = nullptr;
+  float* part = nullptr;
   // workspace
   int cap = 0;
   float *bufA = nullptr, *bufB = nullptr, *cat0 = nullptr, *cat1 = nullptr, *cat2 = nullptr, *gates = nullptr,
@@ -103,6 +119,14 @@ void free_weights(ita_context* c) {
     if (c->bsum[l]) (void)hipFree(c->bsum[l]);
     c->wcat[l] = c->bsum[l] = nullptr;
   }
+  void* extra[] = {c->fold_hi, c->fold_lo, c->fold_bias, c->lw_hi[0], c->lw_lo[0], c->lw_hi[1], c->lw_lo[1],
+                   c->lw_hi[2], c->lw_lo[2]};
+  for (void* q : extra)
+    if (q) (void)hipFree(q);
+  c->fold_hi = c->fold_lo = nullptr;
+  c->fold_bias = nullptr;
+  for (int l = 0; l < 3; ++l) c->lw_hi[l] = c->lw_lo[l] = nullptr;
+  c->folded = false;
   c->dblob = nullptr;
   c->tail_wT = nullptr;
   c->loaded = false;
@@ -114,6 +138,13 @@ void free_workspace(ita_context* c) {
     if (*b) (void)hipFree(*b);
     *b = nullptr;
   }
+  _Float16** hb[] = {&c->x2_hi, &c->x2_lo, &c->c0_hi, &c->c0_lo, &c->c1_hi, &c->c1_lo, &c->c2_hi, &c->c2_lo};
+  for (_Float16** b : hb) {
+    if (*b) (void)hipFree(*b);
+    *b = nullptr;
+  }
+  if (c->part) (void)hipFree(c->part);
+  c->part = nullptr;
   c->cap = 0;
 }
 
@@ -128,6 +159,15 @@ int ensure_workspace(ita_context* c, int B) {
   HIPCHK(hipMalloc(&c->cat1, sizeof(float) * (size_t)B * 256));
   HIPCHK(hipMalloc(&c->cat2, sizeof(float) * (size_t)B * 256));
   HIPCHK(hipMalloc(&c->gates, sizeof(float) * (size_t)B * 512));
+  HIPCHK(hipMalloc(&c->x2_hi, 2 * (size_t)B * KFOLD));
+  HIPCHK(hipMalloc(&c->x2_lo, 2 * (size_t)B * KFOLD));
+  HIPCHK(hipMalloc(&c->c0_hi, 2 * (size_t)B * K0F));
+  HIPCHK(hipMalloc(&c->c0_lo, 2 * (size_t)B * K0F));
+  HIPCHK(hipMalloc(&c->c1_hi, 2 * (size_t)B * 256));
+  HIPCHK(hipMalloc(&c->c1_lo, 2 * (size_t)B * 256));
+  HIPCHK(hipMalloc(&c->c2_hi, 2 * (size_t)B * 256));
+  HIPCHK(hipMalloc(&c->c2_lo, 2 * (size_t)B * 256));
+  HIPCHK(hipMalloc(&c->part, sizeof(float) * (size_t)NSPLIT * B * 512));
   c->cap = B;
   return ITA_OK;
 }
@@ -178,7 +218,7 @@ int launch_mha(ita_context* c, int layer, const float* x, float* y, int B, bool 
 }
 
 int launch_ffn(ita_context* c, int layer, const float* x, float* y, int B, bool fuse, const ita_ffn_taps* t,
-               hipStream_t s) {
+               hipStream_t s, _Float16* y_hi = nullptr, _Float16* y_lo = nullptr) {
   const Layer& L = c->layers[layer];
   if (fuse && !L.n2w) return fail(ITA_ERR_BAD_BLOB, "norm2 parameters missing from the blob");
   ItaFfnArgs a{};
@@ -186,6 +226,7 @@ int launch_ffn(ita_context* c, int layer, const float* x, float* y, int B, bool 
   a.inv_sx = L.fscal[ITA_F_INV_SX]; a.m1 = L.fscal[ITA_F_M1]; a.m2 = L.fscal[ITA_F_M2]; a.s2 = L.fscal[ITA_F_S2];
   a.ln_w = L.n2w; a.ln_b = L.n2b; a.B = B; a.fuse_ln = fuse ? 1 : 0;
   if (t) { a.t_xq = t->x_q; a.t_h = t->h; a.t_out = t->out_q; }
+  a.y_hi = y_hi; a.y_lo = y_lo;
   const int grid = B < 2 * c->num_cus ? B : 2 * c->num_cus;
   if (c->hdr.E == 64) {
     hipLaunchKernelGGL(ita_ffn_kernel<64>, dim3(grid), dim3(512), ItaFfnLds<64>::TOTAL, s, a);
@@ -231,6 +272,94 @@ int launch_gemm(const float* A, int lda, const float* W, int ldw, const float* b
   return ITA_OK;
 }
 
+template <int BM, int BN>
+int launch_gemm_split(const _Float16* a_hi, const _Float16* a_lo, int lda, const _Float16* w_hi, const _Float16* w_lo,
+                      int ldw, float* out, int M, int N, int K, int nsplit, hipStream_t s) {
+  if (N % BN || K % (64 * nsplit)) return fail(ITA_ERR_UNSUPPORTED, "split gemm shape");
+  ItaGemmSplitArgs g{a_hi, a_lo, lda, w_hi, w_lo, ldw, out, M, N, K, nsplit};
+  constexpr int lds_bytes = ItaGemmSplitLds<BM, BN>::TOTAL;
+  auto kern = ita_gemm_f16x3_kernel<BM, BN>;
+  hipLaunchKernelGGL(kern, dim3(N / BN, (M + BM - 1) / BM, nsplit), dim3(256), lds_bytes, s, g);
+  HIPCHK(hipGetLastError());
+  return ITA_OK;
+}
+
+uint16_t float_to_half(float f);
+float half_to_float(uint16_t hbits);
+
+// hi/lo f16 planes of w * 2^e, e chosen so that max|w| * 2^e lies in [512, 1024)
+int split_upload(const std::vector<float>& w, _Float16** d_hi, _Float16** d_lo, float* inv_scale) {
+  float mx = 0.0f;
+  for (float v : w) mx = fabsf(v) > mx ? fabsf(v) : mx;
+  int e = 0;
+  if (mx > 0.0f) {
+    int ex;
+    frexpf(mx, &ex);       // mx = m * 2^ex, m in [0.5, 1)
+    e = 10 - ex;
+  }
+  const float sc = ldexpf(1.0f, e);
+  *inv_scale = ldexpf(1.0f, -e);
+  std::vector<uint16_t> hi(w.size()), lo(w.size());
+  for (size_t i = 0; i < w.size(); ++i) {
+    const float v = w[i] * sc;
+    hi[i] = float_to_half(v);
+    lo[i] = float_to_half(v - half_to_float(hi[i]));
+  }
+  HIPCHK(hipMalloc(d_hi, w.size() * 2));
+  HIPCHK(hipMalloc(d_lo, w.size() * 2));
+  HIPCHK(hipMemcpy(*d_hi, hi.data(), w.size() * 2, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(*d_lo, lo.data(), w.size() * 2, hipMemcpyHostToDevice));
+  return ITA_OK;
+}
+
+int launch_tail(ita_context* c, const float* x, float* feat, int ld, int B, hipStream_t s);
+int launch_gemm(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N,
+                int K, hipStream_t s);
+
+// Folds PixelShuffle/Upsample/concat/conv3x3 and the decoder Linear into Wfold[512][8192] by
+// pushing unit impulses through the exact f32 kernels (bias-free), and dec(tail(0)) as the bias.
+int build_fold(ita_context* c) {
+  const int CH = 1024;
+  float *imp = nullptr, *feat = nullptr, *mt = nullptr, *zero = nullptr;
+  HIPCHK(hipMalloc(&imp, sizeof(float) * (size_t)CH * KFOLD));
+  HIPCHK(hipMalloc(&feat, sizeof(float) * (size_t)CH * 4608));
+  HIPCHK(hipMalloc(&mt, sizeof(float) * (size_t)KFOLD * 512));
+  HIPCHK(hipMalloc(&zero, sizeof(float) * 16));
+  HIPCHK(hipMemset(zero, 0, sizeof(float) * 16));
+  const float* real_cb = c->tail_b;
+  int rc = ITA_OK;
+  c->tail_b = zero;                       // bias-free pass: column i of Wfold = dec_nobias(tail_nobias(e_i))
+  for (int c0 = 0; c0 < KFOLD && !rc; c0 += CH) {
+    const size_t n = (size_t)CH * KFOLD;
+    hipLaunchKernelGGL(ita_impulse_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, imp, CH, KFOLD, c0);
+    if ((rc = launch_tail(c, imp, feat, 4608, CH, nullptr))) break;
+    rc = launch_gemm(feat, 4608, c->dec_w, 4608, nullptr, mt + (size_t)c0 * 512, 512, CH, 512, 4608, nullptr);
+  }
+  c->tail_b = real_cb;
+  std::vector<float> hmt((size_t)KFOLD * 512), hb(512);
+  if (!rc) {
+    // bias' = dec(tail(0)) with the real biases
+    HIPCHK(hipMemset(imp, 0, sizeof(float) * KFOLD));
+    if (!(rc = launch_tail(c, imp, feat, 4608, 1, nullptr)))
+      rc = launch_gemm(feat, 4608, c->dec_w, 4608, c->dec_b, imp, 512, 1, 512, 4608, nullptr);
+  }
+  if (!rc) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(hb.data(), imp, 512 * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hmt.data(), mt, hmt.size() * sizeof(float), hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(imp); (void)hipFree(feat); (void)hipFree(mt); (void)hipFree(zero);
+  if (rc) return rc;
+  std::vector<float> wf((size_t)512 * KFOLD);
+  for (int k = 0; k < KFOLD; ++k)
+    for (int j = 0; j < 512; ++j) wf[(size_t)j * KFOLD + k] = hmt[(size_t)k * 512 + j];
+  if ((rc = split_upload(wf, &c->fold_hi, &c->fold_lo, &c->fold_inv_scale))) return rc;
+  HIPCHK(hipMalloc(&c->fold_bias, 512 * sizeof(float)));
+  HIPCHK(hipMemcpy(c->fold_bias, hb.data(), 512 * sizeof(float), hipMemcpyHostToDevice));
+  c->folded = true;
+  return ITA_OK;
+}
+
 int dispatch_host(const uint16_t* in, uint16_t* out, bool ffn);
 
 }  // namespace
@@ -265,6 +394,13 @@ int ita_create(ita_handle* out, int device_ordinal) {
   if ((rc = set_lds(ita_tokenizer_kernel<128, true>, ita_tok_lds_bytes<128>()))) { delete c; return rc; }
   if ((rc = set_lds(ita_tokenizer_kernel<128, false>, ita_tok_lds_bytes<128>()))) { delete c; return rc; }
   if ((rc = set_lds(ita_tail_kernel<64>, ita_tail_lds_bytes<64>()))) { delete c; return rc; }
+  {
+    auto k1 = ita_gemm_f16x3_kernel<128, 128>;
+    auto k2 = ita_gemm_f16x3_kernel<64, 64>;
+    constexpr int b1 = ItaGemmSplitLds<128, 128>::TOTAL, b2 = ItaGemmSplitLds<64, 64>::TOTAL;
+    if ((rc = set_lds(k1, b1))) { delete c; return rc; }
+    if ((rc = set_lds(k2, b2))) { delete c; return rc; }
+  }
   *out = c;
   return ITA_OK;
 }
@@ -374,9 +510,19 @@ int ita_load_weights(ita_handle h, const void* blob, size_t nbytes) {
       HIPCHK(hipMemcpy(h->wcat[l], wc.data(), wc.size() * sizeof(float), hipMemcpyHostToDevice));
       HIPCHK(hipMalloc(&h->bsum[l], 512 * sizeof(float)));
       HIPCHK(hipMemcpy(h->bsum[l], bs.data(), 512 * sizeof(float), hipMemcpyHostToDevice));
+      // split-precision planes of the same concatenated matrix (layer 0 padded to K0F)
+      const int kf = l == 0 ? K0F : 256;
+      std::vector<float> wf((size_t)512 * kf, 0.0f);
+      for (int j = 0; j < 512; ++j) memcpy(&wf[(size_t)j * kf], &wc[(size_t)j * kp], sizeof(float) * (in + 128));
+      int rc2 = split_upload(wf, &h->lw_hi[l], &h->lw_lo[l], &h->lw_inv_scale[l]);
+      if (rc2) { free_weights(h); return rc2; }
     }
   }
   h->loaded = true;
+  if (hdr.has_tail && hdr.E == 64 && h->tail_wT && h->dec_w && h->lw_hi[0]) {
+    int rc2 = build_fold(h);
+    if (rc2) { free_weights(h); return rc2; }
+  }
   return ITA_OK;
 }
 
@@ -456,6 +602,8 @@ int ita_vitlstm_forward(ita_handle h, const void* image, int image_dtype, const 
   hipStream_t s = (hipStream_t)stream;
   const int B = batch;
   const size_t tokb = sizeof(float) * (size_t)B * 128 * h->hdr.E;
+  const bool fast = h->tail_mode == 1 && h->folded;
+  if (fast && h_out == h_in) return fail(ITA_ERR_INVALID_ARG, "hidden_out_h must not alias hidden_in_h in f16x3 tail mode");
   const int ev_per_fwd = 5 + 2 * h->hdr.num_layers;
   hipEvent_t* ev = (h->prof && h->prof_n < h->prof_max) ? &h->prof_ev[(size_t)h->prof_n * ev_per_fwd] : nullptr;
   int evi = 0;
@@ -469,38 +617,69 @@ int ita_vitlstm_forward(ita_handle h, const void* image, int image_dtype, const 
     MARK();
     if (taps && taps->x1 && l == h->hdr.num_layers - 1)
       HIPCHK(hipMemcpyAsync(taps->x1, h->bufB, tokb, hipMemcpyDeviceToDevice, s));
-    if ((rc = launch_ffn(h, l, h->bufB, h->bufA, B, true, nullptr, s))) return rc;
+    const bool last = l == h->hdr.num_layers - 1;
+    if ((rc = launch_ffn(h, l, h->bufB, (fast && last && !(taps && taps->x2)) ? nullptr : h->bufA, B, true, nullptr, s,
+                         fast && last ? h->x2_hi : nullptr, fast && last ? h->x2_lo : nullptr))) return rc;
     MARK();
   }
   if (taps && taps->x2) HIPCHK(hipMemcpyAsync(taps->x2, h->bufA, tokb, hipMemcpyDeviceToDevice, s));
+  if (fast) {
+    // folded tail+decoder: dec = x2 . Wfold^T + bias'   (x2 planes were written by the last FFN)
+    if ((rc = launch_gemm_split<128, 128>(h->x2_hi, h->x2_lo, KFOLD, h->fold_hi, h->fold_lo, KFOLD, h->part, B, 512,
+                                          KFOLD, NSPLIT, s))) return rc;
+    MARK();
+    {
+      ItaDecFinishArgs d{h->part, NSPLIT, h->fold_inv_scale, h->fold_bias, desvel, quat, h_in, h->c0_hi, h->c0_lo, K0F,
+                         taps ? taps->dec : nullptr, B};
+      hipLaunchKernelGGL(ita_dec_finish_kernel, dim3(B), dim3(256), 0, s, d);
+      HIPCHK(hipGetLastError());
+    }
+    MARK();
+    _Float16* chi[3] = {h->c0_hi, h->c1_hi, h->c2_hi};
+    _Float16* clo[3] = {h->c0_lo, h->c1_lo, h->c2_lo};
+    const int kf[3] = {K0F, 256, 256};
+    for (int l = 0; l < 3; ++l) {
+      if ((rc = launch_gemm_split<64, 64>(chi[l], clo[l], kf[l], h->lw_hi[l], h->lw_lo[l], kf[l], h->gates, B, 512,
+                                          kf[l], 1, s))) return rc;
+      ItaLstmCellArgs p{h->gates, h->lw_inv_scale[l], h->bsum[l], c_in + (size_t)l * B * 128,
+                        h_out + (size_t)l * B * 128, c_out + (size_t)l * B * 128,
+                        l < 2 ? chi[l + 1] : nullptr, l < 2 ? clo[l + 1] : nullptr,
+                        l < 2 ? h_in + (size_t)(l + 1) * B * 128 : nullptr,
+                        l == 2 ? h->fc_w : nullptr, l == 2 ? h->fc_b : nullptr, l == 2 ? vel : nullptr, B};
+      hipLaunchKernelGGL(ita_lstm_cell_kernel, dim3(B), dim3(128), 0, s, p);
+      HIPCHK(hipGetLastError());
+    }
+    MARK();
+  } else {
   if ((rc = launch_tail(h, h->bufA, h->feat, 4608, B, s))) return rc;
-  MARK();
-  if (taps && taps->feat)
-    HIPCHK(hipMemcpyAsync(taps->feat, h->feat, sizeof(float) * (size_t)B * 4608, hipMemcpyDeviceToDevice, s));
-  // decoder writes straight into the LSTM layer-0 concat buffer (columns 0..511)
-  if ((rc = launch_gemm(h->feat, 4608, h->dec_w, 4608, h->dec_b, h->cat0, K0P, B, 512, 4608, s))) return rc;
-  MARK();
-  if (taps && taps->dec)
-    HIPCHK(hipMemcpy2DAsync(taps->dec, 512 * sizeof(float), h->cat0, K0P * sizeof(float), 512 * sizeof(float), B,
-                            hipMemcpyDeviceToDevice, s));
-  {
-    ItaLstmPrepArgs p{desvel, quat, h_in, h->cat0, h->cat1, h->cat2, K0P, B};
-    hipLaunchKernelGGL(ita_lstm_prep_kernel, dim3(B), dim3(256), 0, s, p);
+    MARK();
+    if (taps && taps->feat)
+      HIPCHK(hipMemcpyAsync(taps->feat, h->feat, sizeof(float) * (size_t)B * 4608, hipMemcpyDeviceToDevice, s));
+    // decoder writes straight into the LSTM layer-0 concat buffer (columns 0..511)
+    if ((rc = launch_gemm(h->feat, 4608, h->dec_w, 4608, h->dec_b, h->cat0, K0P, B, 512, 4608, s))) return rc;
+    MARK();
+    if (taps && taps->dec)
+      HIPCHK(hipMemcpy2DAsync(taps->dec, 512 * sizeof(float), h->cat0, K0P * sizeof(float), 512 * sizeof(float), B,
+                              hipMemcpyDeviceToDevice, s));
+    {
+      ItaLstmPrepArgs p{desvel, quat, h_in, h->cat0, h->cat1, h->cat2, K0P, B};
+      hipLaunchKernelGGL(ita_lstm_prep_kernel, dim3(B), dim3(256), 0, s, p);
+      HIPCHK(hipGetLastError());
+    }
+    float* cats[3] = {h->cat0, h->cat1, h->cat2};
+    const int kp[3] = {K0P, 256, 256};
+    for (int l = 0; l < 3; ++l) {
+      if ((rc = launch_gemm(cats[l], kp[l], h->wcat[l], kp[l], h->bsum[l], h->gates, 512, B, 512, kp[l], s))) return rc;
+      ItaLstmPointArgs p{h->gates, c_in + (size_t)l * B * 128, h_out + (size_t)l * B * 128, c_out + (size_t)l * B * 128,
+                         l < 2 ? cats[l + 1] : nullptr, 256, B};
+      hipLaunchKernelGGL(ita_lstm_point_kernel, dim3((B * 128 + 255) / 256), dim3(256), 0, s, p);
+      HIPCHK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(ita_fc_kernel, dim3((B * 3 + 63) / 64), dim3(64), 0, s, h_out + (size_t)2 * B * 128, h->fc_w,
+                       h->fc_b, vel, B);
     HIPCHK(hipGetLastError());
+    MARK();
   }
-  float* cats[3] = {h->cat0, h->cat1, h->cat2};
-  const int kp[3] = {K0P, 256, 256};
-  for (int l = 0; l < 3; ++l) {
-    if ((rc = launch_gemm(cats[l], kp[l], h->wcat[l], kp[l], h->bsum[l], h->gates, 512, B, 512, kp[l], s))) return rc;
-    ItaLstmPointArgs p{h->gates, c_in + (size_t)l * B * 128, h_out + (size_t)l * B * 128, c_out + (size_t)l * B * 128,
-                       l < 2 ? cats[l + 1] : nullptr, 256, B};
-    hipLaunchKernelGGL(ita_lstm_point_kernel, dim3((B * 128 + 255) / 256), dim3(256), 0, s, p);
-    HIPCHK(hipGetLastError());
-  }
-  hipLaunchKernelGGL(ita_fc_kernel, dim3((B * 3 + 63) / 64), dim3(64), 0, s, h_out + (size_t)2 * B * 128, h->fc_w,
-                     h->fc_b, vel, B);
-  HIPCHK(hipGetLastError());
-  MARK();
 #undef MARK
   if (ev) ++h->prof_n;
   return ITA_OK;
@@ -549,6 +728,13 @@ int ita_profile_end(ita_handle h, double* stage_ms, int* n_forwards) {
   }
   *n_forwards = h->prof_n;
   h->prof_n = 0;
+  return ITA_OK;
+}
+
+int ita_set_tail_mode(ita_handle h, int mode) {
+  if (!h) return fail(ITA_ERR_INVALID_ARG, "null handle");
+  if (mode != 0 && mode != 1) return fail(ITA_ERR_INVALID_ARG, "mode must be 0 (exact f32) or 1 (folded f16x3)");
+  h->tail_mode = mode;
   return ITA_OK;
 }
 

@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = (
     "ita_abi_version", "ita_create", "ita_destroy", "ita_load_weights", "ita_reserve", "ita_get_dims",
     "ita_last_error", "ita_error_string", "ita_mha_int8", "ita_mha_int8_taps", "ita_ffn_int8", "ita_ffn_int8_taps",
     "ita_encoder_layer", "ita_tokenizer", "ita_fusion_tail", "ita_vitlstm_forward", "ita_bind_dispatch",
-    "ita_profile_begin", "ita_profile_end",
+    "ita_profile_begin", "ita_profile_end", "ita_set_tail_mode",
     "ITASelfAttention_workgroup", "ITASelfAttention_workgroup_expanded", "ITAFeedForward_workgroup",
 )
 
@@ -94,6 +94,7 @@ def lib():
         L.ita_fusion_tail.argtypes = [vp, vp, vp, i, vp]
         L.ita_vitlstm_forward.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, vp, vp, i, C.POINTER(_FwdTaps), vp]
         L.ita_bind_dispatch.argtypes = [vp, i, i]
+        L.ita_set_tail_mode.argtypes = [vp, i]
         L.ita_profile_begin.argtypes = [vp, i]
         L.ita_profile_end.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i)]
         L.ITASelfAttention_workgroup.argtypes = [vp, vp]
@@ -261,6 +262,10 @@ class Engine:
         if taps:
             return vel, (h_out, c_out), tp
         return vel, (h_out, c_out)
+
+    def set_tail_mode(self, mode: int):
+        """1: folded conv+decoder, f16x3 split-precision MFMA tail (default); 0: exact f32 kernels"""
+        _chk(lib().ita_set_tail_mode(self._h, mode))
 
     # ---- per-stage device timing ---------------------------------------------------------
     STAGES = ("tokenizer", "mha", "ffn", "tail", "decoder", "lstm_fc")

@@ -105,6 +105,13 @@ int ita_vitlstm_forward(ita_handle h, const void* image_dev, int image_dtype, co
                         float* output_dev, float* hidden_out_h_dev, float* hidden_out_c_dev, int batch,
                         const ita_forward_taps* taps, void* stream);
 
+/* Arithmetic of the float tail (fusion conv, decoder, LSTM) inside ita_vitlstm_forward:
+ *   1 (default)  conv+decoder folded into one matrix at load time, all tail GEMMs on f16 MFMA with
+ *                split-precision (hi+lo) operands: within 1e-5 of the f32 graph (task tolerance 1e-4)
+ *   0            the f32 kernels in the CPU oracle's operation order: equal to the oracle bit for bit.
+ * In mode 1 hidden_out_h must not alias hidden_in_h. */
+int ita_set_tail_mode(ita_handle h, int mode);
+
 /* ---- per-stage timing (bench.py's roofline leg) -------------------------------------------- */
 /* Between ita_profile_begin and ita_profile_end every ita_vitlstm_forward call records HIP
  * events on ITS OWN stream around each stage; ita_profile_end synchronises them and returns

@@ -160,27 +160,33 @@ def test_float_stages_equal_oracle(torch_cuda, oracle, path):
     eng.close()
 
 
+@pytest.mark.parametrize("mode", [1, 0], ids=["tail_f16x3", "tail_exact_f32"])
 @pytest.mark.parametrize("path", FIX_VIT, ids=_ids(FIX_VIT))
-def test_full_forward_two_steps(torch_cuda, oracle, path):
+def test_full_forward_two_steps(torch_cuda, oracle, path, mode):
+    """mode 1 (default): conv+decoder folded, tail GEMMs on split-precision f16 MFMA; tolerance
+    2e-5 absolute against the oracle (task tolerance for the tail: 1e-4).  mode 0: exact f32
+    kernels, equality.  Everything up to and including x2 is equal to the oracle in both modes."""
     torch = torch_cuda
     d = params.load_fixture(path)
     eng, blob, fp = _engine(d, 64)
+    eng.set_tail_mode(mode)
+    tol = 2e-5 if mode == 1 else 0.0
     cu = lambda a: torch.from_numpy(a).cuda()
     vel0, (h0, c0), tp = eng.forward(cu(d["in0.img_u8"]), cu(d["in0.desvel"]), cu(d["in0.quat"]), taps=True)
     ovel0, oh0, oc0, otp = oracle.forward(blob, d["in0.img_u8"], d["in0.desvel"], d["in0.quat"], taps=True)
-    for k in ("tokens", "x1", "x2", "feat"):
+    for k in ("tokens", "x1", "x2") + (("feat",) if mode == 0 else ()):
         np.testing.assert_array_equal(tp[k].cpu().numpy(), otp[k], err_msg=k)
-    # decoder / LSTM run on f32 MFMA (documented as a k-ordered fmaf chain; tolerance 1e-5 in case
-    # the within-instruction order differs from ascending k)
-    np.testing.assert_allclose(tp["dec"].cpu().numpy(), otp["dec"], atol=1e-5, rtol=0)
-    np.testing.assert_allclose(vel0.cpu().numpy(), ovel0, atol=1e-5, rtol=0)
-    np.testing.assert_allclose(h0.cpu().numpy(), oh0, atol=1e-5, rtol=0)
-    np.testing.assert_allclose(c0.cpu().numpy(), oc0, atol=1e-5, rtol=0)
+    np.testing.assert_allclose(tp["dec"].cpu().numpy(), otp["dec"], atol=tol, rtol=0)
+    np.testing.assert_allclose(vel0.cpu().numpy(), ovel0, atol=tol, rtol=0)
+    np.testing.assert_allclose(h0.cpu().numpy(), oh0, atol=tol, rtol=0)
+    np.testing.assert_allclose(c0.cpu().numpy(), oc0, atol=tol, rtol=0)
+    print(f"\n[tail mode {mode}] max|dec - oracle| = {np.abs(tp['dec'].cpu().numpy() - otp['dec']).max():.3e}, "
+          f"max|h - oracle| = {np.abs(h0.cpu().numpy() - oh0).max():.3e}")
     # second time step, state carried on the device like the reference host carries it
     vel1, (h1, c1) = eng.forward(cu(d["in1.img_u8"]), cu(d["in1.desvel"]), cu(d["in1.quat"]), (h0, c0))
     ovel1, oh1, oc1 = oracle.forward(blob, d["in1.img_u8"], d["in1.desvel"], d["in1.quat"], oh0, oc0)
-    np.testing.assert_allclose(vel1.cpu().numpy(), ovel1, atol=2e-5, rtol=0)
-    np.testing.assert_allclose(h1.cpu().numpy(), oh1, atol=2e-5, rtol=0)
+    np.testing.assert_allclose(vel1.cpu().numpy(), ovel1, atol=2 * tol, rtol=0)
+    np.testing.assert_allclose(h1.cpu().numpy(), oh1, atol=2 * tol, rtol=0)
     # against the reference's own outputs (fixture): int8 flips behind float LayerNorms allowed
     np.testing.assert_allclose(vel0.cpu().numpy(), d["s0.vel"], atol=5e-4, rtol=0)
     np.testing.assert_allclose(vel1.cpu().numpy(), d["s1.vel"], atol=5e-4, rtol=0)
@@ -190,7 +196,7 @@ def test_full_forward_two_steps(torch_cuda, oracle, path):
     v, (hh, cc) = model([cu(d["in0.img_u8"]), cu(d["in0.desvel"])])
     q = np.zeros((2, 4), np.float32); q[:, 0] = 1
     ov, _, _ = oracle.forward(blob, d["in0.img_u8"], d["in0.desvel"], q)
-    np.testing.assert_allclose(v.cpu().numpy(), ov, atol=1e-5, rtol=0)
+    np.testing.assert_allclose(v.cpu().numpy(), ov, atol=2e-5, rtol=0)
     eng.close()
 
 
@@ -199,6 +205,7 @@ def test_decoder_lstm_exactness_report(torch_cuda, oracle):
     torch = torch_cuda
     d = params.load_fixture(FIX_VIT[0])
     eng, blob, fp = _engine(d, 64)
+    eng.set_tail_mode(0)
     cu = lambda a: torch.from_numpy(a).cuda()
     vel, (h, c), tp = eng.forward(cu(d["in0.img_u8"]), cu(d["in0.desvel"]), cu(d["in0.quat"]), taps=True)
     ovel, oh, oc, otp = oracle.forward(blob, d["in0.img_u8"], d["in0.desvel"], d["in0.quat"], taps=True)
@@ -232,8 +239,8 @@ def test_full_size_properties(torch_cuda, oracle):
     sel = [0, 255, 256, 777, 1023]
     ov, oh, oc = oracle.forward(blob, fr["img_u8"][sel], fr["desvel"][sel], fr["quat"][sel],
                                 h.cpu().numpy()[:, sel], c.cpu().numpy()[:, sel])
-    np.testing.assert_allclose(v1.cpu().numpy()[sel], ov, atol=1e-5, rtol=0)
-    np.testing.assert_allclose(c1.cpu().numpy()[:, sel], oc, atol=1e-5, rtol=0)
+    np.testing.assert_allclose(v1.cpu().numpy()[sel], ov, atol=2e-5, rtol=0)
+    np.testing.assert_allclose(c1.cpu().numpy()[:, sel], oc, atol=2e-5, rtol=0)
     eng.close()
 
 
