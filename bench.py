@@ -32,8 +32,8 @@ import numpy as np  # noqa: E402
 # algorithmic work per frame (BASELINE.md section 2 / SURVEY.md section 8(d)); E=64, S=128, P=192, F=256
 STAGE_WORK = {   # stage: (ops per frame, bound, peak in Tera-op/s, arithmetic)
     "tokenizer": (2 * 4.23e6, "mfma", 157.3, "f32"),
-    "mha": (2 * 12.58e6, "mfma", 5000.0, "int8"),
-    "ffn": (2 * 4.19e6, "mfma", 5000.0, "int8"),
+    # int8 MHA + int8 FFN (+ both LayerNorms) are ONE launch: ita_encoder_kernel
+    "encoder": (2 * (12.58e6 + 4.19e6), "mfma", 5000.0, "int8"),
     # fusion conv + decoder run as ONE folded GEMM on split-precision f16 MFMA (priced against the
     # dense f16 peak with the reference graph's algorithmic flops, not the 3x split products)
     "tail_decoder": (2 * (3.32e6 + 2.36e6), "mfma", 2500.0, "f16x3"),
@@ -132,6 +132,7 @@ def main():
     if rank == 0:
         per = {k: v / max(nprof, 1) for k, v in stage_ms.items()}
         per["tail_decoder"] = per.pop("tail") + per.pop("decoder")
+        per["encoder"] = per.pop("mha") + per.pop("ffn")
         dom = max(per, key=per.get)
         ops, bound, peak, arith = STAGE_WORK[dom]
         achieved = ops * B / (per[dom] * 1e-3) / 1e12

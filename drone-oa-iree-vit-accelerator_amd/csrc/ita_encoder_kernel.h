@@ -1,0 +1,349 @@
+// ita_encoder_kernel.h -- one whole encoder layer per launch (E = 64, the ITAViTLSTM shape):
+//
+//   x1 = LayerNorm1(x + ITASelfAttention_QAT(x));  y = LayerNorm2(x1 + ITAFeedForward_QAT(x1))
+//   (reference models/ITA_single_layer_upsample_shuffle/QAT/model.py:100-113,
+//    models/ITA/QAT/layers.py:61-75,101-127, models/ITA/QAT/ITA_softmax.py:51-61)
+//
+// Same arithmetic, bit for bit, as ita_mha_kernel + ita_ffn_kernel (ita_int8_kernels.h); what
+// changes is where the operands live, because those two kernels are bound by the latency of
+// their global weight loads, not by MFMA or VALU issue:
+//   * persistent workgroups (one per CU) keep Wq/Wk/Wv/W1 and all biases in LDS as chunk-major
+//     int8 images for the whole launch; every wave always computes the same out_proj / fc2 output
+//     tile, so its Wo / W2 fragments stay in registers (24 + 32 VGPRs);
+//   * x1 never leaves the CU: LayerNorm1's result stays in the registers of the thread that
+//     quantises it for the FFN;
+//   * the next frame's tokens are fetched into registers while the current frame is in the
+//     attention phase.
+// LDS: x_q/out_q 8 KB | Q(ctx) 24 KB | K 24 KB | V^T 24 KB (K..V^T reused for the 32 KB FFN hidden
+// layer) | colsum | Wq Wk Wv 36 KB | W1 16 KB | biases 3.75 KB  = 140 032 B of the CU's 160 KB.
+#pragma once
+#include "ita_int8_kernels.h"
+
+struct ItaEncArgs {
+  const float* x;        // (B,128,64)
+  float* y;              // (B,128,64) f32, may be null when planes are given
+  _Float16 *y_hi, *y_lo; // optional f16 hi/lo planes of y
+  float* x1_tap;         // optional (B,128,64): LayerNorm1 output
+  const int8_t *wq, *wk, *wv, *wo, *w1, *w2;
+  const int32_t *bq, *bk, *bv, *bo, *b1, *b2;
+  float inv_sx, mq, mk, mv, ml, mc, mo, so;      // attention scalars (ita_weights.h)
+  float f_inv_sx, m1, m2, s2;                    // FFN scalars
+  const float *n1w, *n1b, *n2w, *n2b;
+  int B;
+};
+
+struct ItaEncLds {
+  static constexpr int S = 128, E = 64, P = 192, F = 256;
+  static constexpr int XQ = 0;                    // int8 [4][128][16]; also the block outputs (out_q)
+  static constexpr int Q = XQ + S * E;            // int8 [12][128][16]; context overwrites it
+  static constexpr int K = Q + S * P;
+  static constexpr int VT = K + S * P;            // int8 [8][192][16]
+  static constexpr int H = K;                     // int8 [16][128][16] FFN hidden (K and V^T are dead by then)
+  static constexpr int COLSUM = VT + P * S;       // int32 [192]
+  static constexpr int WQ = COLSUM + P * 4;       // int8 [4][192][16] x3
+  static constexpr int WK = WQ + P * E;
+  static constexpr int WV = WK + P * E;
+  static constexpr int W1 = WV + P * E;           // int8 [4][256][16]
+  static constexpr int BIAS = W1 + F * E;         // int32: bq 192 | bk 192 | bv 192 | bo 64 | b1 256 | b2 64
+  static constexpr int TOTAL = BIAS + (3 * P + E + F + E) * 4;
+};
+static_assert(ItaEncLds::H + 128 * 256 <= ItaEncLds::COLSUM, "FFN hidden layer must fit in the K + V^T region");
+static_assert(ItaEncLds::TOTAL <= 160 * 1024, "LDS budget");
+
+// weights [rows][K] row-major in global -> chunk-major LDS image
+template <int KB>
+__device__ __forceinline__ void load_weight_cm(const int8_t* __restrict__ w, int rows, char* dst, int tid) {
+  for (int p = tid; p < rows * (KB / 16); p += 512) {
+    const int row = p / (KB / 16), ch = p - row * (KB / 16);
+    *(i32x4*)(dst + ((ch * rows + row) << 4)) = *(const i32x4*)(w + (size_t)row * KB + 16 * ch);
+  }
+}
+
+// 32x32 tile: A = weights from a chunk-major LDS image (WROWS rows), Bt = activations (128 rows)
+template <int KB, int WROWS>
+__device__ __forceinline__ i32x16 tile_wlds_x(const char* lds_w, int f0, const int* lds_bias, const char* lds_act,
+                                              int t0, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  i32x16 acc;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const i32x4 b4 = *(const i32x4*)(lds_bias + f0 + 8 * g + 4 * h);
+    acc[4 * g] = b4.x; acc[4 * g + 1] = b4.y; acc[4 * g + 2] = b4.z; acc[4 * g + 3] = b4.w;
+  }
+#pragma unroll
+  for (int ks = 0; ks < KB / 32; ++ks) {
+    const i32x4 a = lds_frag(lds_w, cm_off(f0 + r, 32 * ks + 16 * h, WROWS));
+    const i32x4 b = lds_frag(lds_act, cm_off(t0 + r, 32 * ks + 16 * h, 128));
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// 32x32 tile with the weight fragments already in registers
+template <int KSTEPS>
+__device__ __forceinline__ i32x16 tile_wreg_x(const i32x4 (&wf)[KSTEPS], const int* lds_bias, int f0,
+                                              const char* lds_act, int t0, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  i32x16 acc;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const i32x4 b4 = *(const i32x4*)(lds_bias + f0 + 8 * g + 4 * h);
+    acc[4 * g] = b4.x; acc[4 * g + 1] = b4.y; acc[4 * g + 2] = b4.z; acc[4 * g + 3] = b4.w;
+  }
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    const i32x4 b = lds_frag(lds_act, cm_off(t0 + r, 32 * ks + 16 * h, 128));
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[ks], b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
+  using L = ItaEncLds;
+  constexpr int S = 128, E = 64, P = 192, F = 256, EC = 16;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int token = tid >> 2, qtr = tid & 3;
+  const int r = lane & 31, h = lane >> 5;
+  int* colsum = (int*)(lds + L::COLSUM);
+  int* bias = (int*)(lds + L::BIAS);
+  const int *l_bq = bias, *l_bk = bias + P, *l_bv = bias + 2 * P, *l_bo = bias + 3 * P, *l_b1 = bias + 3 * P + E,
+            *l_b2 = bias + 3 * P + E + F;
+
+  // ---- once per workgroup: weights and biases
+  load_weight_cm<E>(a.wq, P, lds + L::WQ, tid);
+  load_weight_cm<E>(a.wk, P, lds + L::WK, tid);
+  load_weight_cm<E>(a.wv, P, lds + L::WV, tid);
+  load_weight_cm<E>(a.w1, F, lds + L::W1, tid);
+  for (int i = tid; i < 3 * P + E + F + E; i += 512) {
+    int v;
+    if (i < P) v = a.bq[i];
+    else if (i < 2 * P) v = a.bk[i - P];
+    else if (i < 3 * P) v = a.bv[i - 2 * P];
+    else if (i < 3 * P + E) v = a.bo[i - 3 * P];
+    else if (i < 3 * P + E + F) v = a.b1[i - 3 * P - E];
+    else v = a.b2[i - 3 * P - E - F];
+    bias[i] = v;
+  }
+  // this wave's out_proj / fc2 output tile is the same for every frame: features et*32.., tokens tt*32..
+  const int et = wave >> 2, tt = wave & 3;
+  i32x4 wo_f[6], w2_f[8];
+#pragma unroll
+  for (int ks = 0; ks < 6; ++ks) wo_f[ks] = gl_frag(a.wo + (size_t)(et * 32 + r) * P + 32 * ks + 16 * h);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) w2_f[ks] = gl_frag(a.w2 + (size_t)(et * 32 + r) * F + 32 * ks + 16 * h);
+
+  float xr[EC];
+  if ((int)blockIdx.x < a.B) {
+    const float* xrow = a.x + ((size_t)blockIdx.x * S + token) * E + qtr * EC;
+#pragma unroll
+    for (int i = 0; i < EC; i += 4) {
+      const f32x4 v = *(const f32x4*)(xrow + i);
+      xr[i] = v.x; xr[i + 1] = v.y; xr[i + 2] = v.z; xr[i + 3] = v.w;
+    }
+  }
+
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    // ---------------- phase 0: quantise (xr holds this thread's 16 channels of one token)
+    {
+      i32x4 pk;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        pk[j] = (int)pack4(q_bits(xr[4 * j], a.inv_sx), q_bits(xr[4 * j + 1], a.inv_sx),
+                           q_bits(xr[4 * j + 2], a.inv_sx), q_bits(xr[4 * j + 3], a.inv_sx));
+      *(i32x4*)(lds + L::XQ + cm_off(token, qtr * EC, 128)) = pk;
+    }
+    if (tid < P) colsum[tid] = 0;
+    __syncthreads();
+
+    // ---------------- phase P: Q, K, V projections
+    {
+      const int half = wave >> 2;
+      for (int ft = 9 * half; ft < 9 * half + 9; ++ft) {
+        const int mat = ft / 6, dt = ft - 6 * mat;
+        if (mat < 2) {
+          const i32x16 acc = tile_wlds_x<E, P>(lds + (mat == 0 ? L::WQ : L::WK), dt * 32, mat == 0 ? l_bq : l_bk,
+                                               lds + L::XQ, tt * 32, lane);
+          store_tile_fx<true>(acc, mat == 0 ? a.mq : a.mk, -128.0f, lds + (mat == 0 ? L::Q : L::K), 0, dt * 32,
+                              tt * 32, lane, nullptr, 0);
+        } else {
+          const int d = dt * 32 + r;
+          const int bias_d = l_bv[d];
+          i32x16 acc;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[i] = bias_d;
+#pragma unroll
+          for (int ks = 0; ks < E / 32; ++ks) {
+            const i32x4 xa = lds_frag(lds + L::XQ, cm_off(tt * 32 + r, 32 * ks + 16 * h, 128));
+            const i32x4 wb = lds_frag(lds + L::WV, cm_off(d, 32 * ks + 16 * h, P));
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa, wb, acc, 0, 0, 0);
+          }
+          int csum = 0;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const unsigned b0 = rq_bits(acc[4 * g], a.mv), b1 = rq_bits(acc[4 * g + 1], a.mv),
+                           b2 = rq_bits(acc[4 * g + 2], a.mv), b3 = rq_bits(acc[4 * g + 3], a.mv);
+            csum += bits_to_int(b0) + bits_to_int(b1) + bits_to_int(b2) + bits_to_int(b3);
+            const int kb = tt >> 1, kq = 2 * (g & 1) + h, t = 2 * (tt & 1) + (g >> 1);
+            *(unsigned*)(lds + L::VT + (((kb * 4 + kq) * P + d) << 4) + 4 * t) = pack4(b0, b1, b2, b3);
+          }
+          csum += __shfl_xor(csum, 32);
+          if (h == 0) atomicAdd(&colsum[d], csum);
+        }
+      }
+    }
+    __syncthreads();
+
+    // prefetch the next frame's tokens; they are consumed at the next phase 0
+    float xn[EC];
+    {
+      const int nb = b + gridDim.x;
+      if (nb < a.B) {
+        const float* xrow = a.x + ((size_t)nb * S + token) * E + qtr * EC;
+#pragma unroll
+        for (int i = 0; i < EC; i += 4) {
+          const f32x4 v = *(const f32x4*)(xrow + i);
+          xn[i] = v.x; xn[i + 1] = v.y; xn[i + 2] = v.z; xn[i + 3] = v.w;
+        }
+      }
+    }
+
+    // ---------------- phase A: 16 queries per wave, logits and probabilities stay in registers
+    {
+      const int q0 = wave * 16, qi = lane & 15, kq = lane >> 4;
+      i32x4 qf[3];
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) qf[ks] = lds_frag(lds + L::Q, cm_off(q0 + qi, 64 * ks + 16 * kq, 128));
+      int v[32];
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt) {
+        i32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+          const i32x4 kf = lds_frag(lds + L::K, cm_off(kt * 16 + qi, 64 * ks + 16 * kq, 128));
+          acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf, qf[ks], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[4 * kt + i] = bits_to_int(rq_bits(acc[i], a.ml));
+      }
+      int m = v[0];
+#pragma unroll
+      for (int j = 1; j < 32; ++j) m = max(m, v[j]);
+      m = max(m, __shfl_xor(m, 16));
+      m = max(m, __shfl_xor(m, 32));
+      int sum = 0;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        v[j] = min(m - v[j], 23);
+        sum += 256 >> v[j];
+      }
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      sum = max(sum, 1);
+      const int inv_hi = ((int)floorf((1.0f / (float)sum) * 16711680.0f)) >> 8;
+      i32x4 pf[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int kt = 4 * kb + t;
+          pf[kb][t] = (int)(pack4(inv_hi >> v[4 * kt], inv_hi >> v[4 * kt + 1], inv_hi >> v[4 * kt + 2],
+                                  inv_hi >> v[4 * kt + 3]) ^ 0x80808080u);
+        }
+#pragma unroll
+      for (int dt = 0; dt < 12; ++dt) {
+        i32x4 acc = *(const i32x4*)(colsum + dt * 16 + 4 * kq);
+        acc = acc << 7;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          const i32x4 vf = lds_frag(lds + L::VT, ((((kb * 4 + kq) * P) + dt * 16 + qi) << 4));
+          acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pf[kb], acc, 0, 0, 0);
+        }
+        *(unsigned*)(lds + L::Q + cm_off(q0 + qi, dt * 16 + 4 * kq, 128)) =
+            pack4(rq_bits(acc[0], a.mc), rq_bits(acc[1], a.mc), rq_bits(acc[2], a.mc), rq_bits(acc[3], a.mc));
+      }
+    }
+    __syncthreads();
+
+    // ---------------- phase O: out_proj, weights in registers -> out_q (chunk-major, over x_q)
+    {
+      const i32x16 acc = tile_wreg_x<6>(wo_f, l_bo, et * 32, lds + L::Q, tt * 32, lane);
+      store_tile_fx<true>(acc, a.mo, -128.0f, lds + L::XQ, 0, et * 32, tt * 32, lane, nullptr, 0);
+    }
+    __syncthreads();
+
+    // ---------------- phase L1: x1 = LN1(x + dequant(out_q)); quantise x1 for the FFN in place
+    float x1[EC];
+    {
+      const i32x4 pk = *(const i32x4*)(lds + L::XQ + cm_off(token, qtr * EC, 128));
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int vv = (int)(int8_t)((unsigned)pk[j >> 2] >> (8 * (j & 3)));
+        x1[j] = xr[j] + (float)vv * a.so;
+      }
+      layernorm_lanes<E, 4>(x1, a.n1w, a.n1b, qtr * EC);
+      if (a.x1_tap) {
+        float* o = a.x1_tap + ((size_t)b * S + token) * E + qtr * EC;
+#pragma unroll
+        for (int i = 0; i < EC; i += 4) *(f32x4*)(o + i) = (f32x4){x1[i], x1[i + 1], x1[i + 2], x1[i + 3]};
+      }
+      i32x4 q4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        q4[j] = (int)pack4(q_bits(x1[4 * j], a.f_inv_sx), q_bits(x1[4 * j + 1], a.f_inv_sx),
+                           q_bits(x1[4 * j + 2], a.f_inv_sx), q_bits(x1[4 * j + 3], a.f_inv_sx));
+      *(i32x4*)(lds + L::XQ + cm_off(token, qtr * EC, 128)) = q4;   // same 16 bytes this thread just read
+    }
+    __syncthreads();
+
+    // ---------------- phase F1: fc1 + ReLU -> hidden (chunk-major over the dead K / V^T images)
+    for (int ft = (wave >> 2) * 4; ft < (wave >> 2) * 4 + 4; ++ft) {
+      const i32x16 acc = tile_wlds_x<E, F>(lds + L::W1, ft * 32, l_b1, lds + L::XQ, tt * 32, lane);
+      store_tile_fx<true>(acc, a.m1, 0.0f, lds + L::H, 0, ft * 32, tt * 32, lane, nullptr, 0);
+    }
+    __syncthreads();
+
+    // ---------------- phase F2: fc2, weights in registers -> out_q (over the FFN's x_q)
+    {
+      const i32x16 acc = tile_wreg_x<8>(w2_f, l_b2, et * 32, lds + L::H, tt * 32, lane);
+      store_tile_fx<true>(acc, a.m2, -128.0f, lds + L::XQ, 0, et * 32, tt * 32, lane, nullptr, 0);
+    }
+    __syncthreads();
+
+    // ---------------- phase L2: y = LN2(x1 + dequant(out_q))
+    {
+      const i32x4 pk = *(const i32x4*)(lds + L::XQ + cm_off(token, qtr * EC, 128));
+      float y[EC];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int vv = (int)(int8_t)((unsigned)pk[j >> 2] >> (8 * (j & 3)));
+        y[j] = x1[j] + (float)vv * a.s2;
+      }
+      layernorm_lanes<E, 4>(y, a.n2w, a.n2b, qtr * EC);
+      const size_t o = ((size_t)b * S + token) * E + qtr * EC;
+      if (a.y) {
+#pragma unroll
+        for (int i = 0; i < EC; i += 4) *(f32x4*)(a.y + o + i) = (f32x4){y[i], y[i + 1], y[i + 2], y[i + 3]};
+      }
+      if (a.y_hi) {
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+        for (int i = 0; i < EC; i += 8) {
+          h8 vh, vl;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const _Float16 hh = (_Float16)y[i + j];
+            vh[j] = hh;
+            vl[j] = (_Float16)(y[i + j] - (float)hh);
+          }
+          *(h8*)(a.y_hi + o + i) = vh;
+          *(h8*)(a.y_lo + o + i) = vl;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < EC; ++i) xr[i] = xn[i];
+    // phase 0 of the next frame writes x_q, which phase L2 above has just read: the read and the
+    // write of a given 16-byte slot are by the same thread, so no barrier is needed here
+  }
+}

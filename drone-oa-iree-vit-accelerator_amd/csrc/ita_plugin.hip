@@ -14,6 +14,7 @@
 
 #include "../../include/ita_mi355x.h"
 #include "../../include/ita_weights.h"
+#include "ita_encoder_kernel.h"
 #include "ita_f16x3_kernels.h"
 #include "ita_f32_kernels.h"
 #include "ita_int8_kernels.h"
@@ -237,6 +238,26 @@ int launch_ffn(ita_context* c, int layer, const float* x, float* y, int B, bool 
   return ITA_OK;
 }
 
+// whole encoder layer in one launch (E = 64)
+int launch_encoder(ita_context* c, int layer, const float* x, float* y, _Float16* y_hi, _Float16* y_lo, float* x1_tap,
+                   int B, hipStream_t s) {
+  const Layer& L = c->layers[layer];
+  if (!L.n1w || !L.n2w) return fail(ITA_ERR_BAD_BLOB, "LayerNorm parameters missing from the blob");
+  ItaEncArgs a{};
+  a.x = x; a.y = y; a.y_hi = y_hi; a.y_lo = y_lo; a.x1_tap = x1_tap;
+  a.wq = L.wq; a.wk = L.wk; a.wv = L.wv; a.wo = L.wo; a.w1 = L.w1; a.w2 = L.w2;
+  a.bq = L.bq; a.bk = L.bk; a.bv = L.bv; a.bo = L.bo; a.b1 = L.b1; a.b2 = L.b2;
+  a.inv_sx = L.ascal[ITA_A_INV_SX]; a.mq = L.ascal[ITA_A_MQ]; a.mk = L.ascal[ITA_A_MK]; a.mv = L.ascal[ITA_A_MV];
+  a.ml = L.ascal[ITA_A_ML]; a.mc = L.ascal[ITA_A_MC]; a.mo = L.ascal[ITA_A_MO]; a.so = L.ascal[ITA_A_SO];
+  a.f_inv_sx = L.fscal[ITA_F_INV_SX]; a.m1 = L.fscal[ITA_F_M1]; a.m2 = L.fscal[ITA_F_M2]; a.s2 = L.fscal[ITA_F_S2];
+  a.n1w = L.n1w; a.n1b = L.n1b; a.n2w = L.n2w; a.n2b = L.n2b;
+  a.B = B;
+  const int grid = B < c->num_cus ? B : c->num_cus;
+  hipLaunchKernelGGL(ita_encoder_kernel, dim3(grid), dim3(512), ItaEncLds::TOTAL, s, a);
+  HIPCHK(hipGetLastError());
+  return ITA_OK;
+}
+
 int launch_tokenizer(ita_context* c, const void* img, int dtype, float* tokens, int B, hipStream_t s) {
   if (!c->tok_w) return fail(ITA_ERR_BAD_BLOB, "tokenizer parameters missing from the blob");
   ItaTokArgs a{img, c->tok_w, c->tok_b, c->tok_lw, c->tok_lb, tokens, B};
@@ -394,6 +415,7 @@ int ita_create(ita_handle* out, int device_ordinal) {
   if ((rc = set_lds(ita_tokenizer_kernel<128, true>, ita_tok_lds_bytes<128>()))) { delete c; return rc; }
   if ((rc = set_lds(ita_tokenizer_kernel<128, false>, ita_tok_lds_bytes<128>()))) { delete c; return rc; }
   if ((rc = set_lds(ita_tail_kernel<64>, ita_tail_lds_bytes<64>()))) { delete c; return rc; }
+  if ((rc = set_lds(ita_encoder_kernel, ItaEncLds::TOTAL))) { delete c; return rc; }
   {
     auto k1 = ita_gemm_f16x3_kernel<128, 128>;
     auto k2 = ita_gemm_f16x3_kernel<64, 64>;
@@ -569,6 +591,7 @@ int ita_encoder_layer(ita_handle h, int layer, const float* x, float* y, int bat
   int rc = check(h, batch);
   if (rc) return rc;
   if (!x || !y || layer < 0 || layer >= h->hdr.num_layers) return fail(ITA_ERR_INVALID_ARG, "bad pointer or layer");
+  if (h->hdr.E == 64) return launch_encoder(h, layer, x, y, nullptr, nullptr, nullptr, batch, (hipStream_t)stream);
   if ((rc = launch_mha(h, layer, x, y, batch, true, nullptr, (hipStream_t)stream))) return rc;
   return launch_ffn(h, layer, y, y, batch, true, nullptr, (hipStream_t)stream);
 }
@@ -613,14 +636,22 @@ int ita_vitlstm_forward(ita_handle h, const void* image, int image_dtype, const 
   MARK();
   if (taps && taps->tokens) HIPCHK(hipMemcpyAsync(taps->tokens, h->bufA, tokb, hipMemcpyDeviceToDevice, s));
   for (int l = 0; l < h->hdr.num_layers; ++l) {
-    if ((rc = launch_mha(h, l, h->bufA, h->bufB, B, true, nullptr, s))) return rc;
-    MARK();
-    if (taps && taps->x1 && l == h->hdr.num_layers - 1)
-      HIPCHK(hipMemcpyAsync(taps->x1, h->bufB, tokb, hipMemcpyDeviceToDevice, s));
     const bool last = l == h->hdr.num_layers - 1;
-    if ((rc = launch_ffn(h, l, h->bufB, (fast && last && !(taps && taps->x2)) ? nullptr : h->bufA, B, true, nullptr, s,
-                         fast && last ? h->x2_hi : nullptr, fast && last ? h->x2_lo : nullptr))) return rc;
-    MARK();
+    const bool planes = fast && last;
+    float* yout = (planes && !(taps && taps->x2)) ? nullptr : h->bufA;
+    if (h->hdr.E == 64) {     // fused encoder layer, in place on bufA
+      if ((rc = launch_encoder(h, l, h->bufA, yout, planes ? h->x2_hi : nullptr, planes ? h->x2_lo : nullptr,
+                               (taps && last) ? taps->x1 : nullptr, B, s))) return rc;
+      MARK();
+      MARK();
+    } else {
+      if ((rc = launch_mha(h, l, h->bufA, h->bufB, B, true, nullptr, s))) return rc;
+      MARK();
+      if (taps && taps->x1 && last) HIPCHK(hipMemcpyAsync(taps->x1, h->bufB, tokb, hipMemcpyDeviceToDevice, s));
+      if ((rc = launch_ffn(h, l, h->bufB, yout, B, true, nullptr, s, planes ? h->x2_hi : nullptr,
+                           planes ? h->x2_lo : nullptr))) return rc;
+      MARK();
+    }
   }
   if (taps && taps->x2) HIPCHK(hipMemcpyAsync(taps->x2, h->bufA, tokb, hipMemcpyDeviceToDevice, s));
   if (fast) {
