@@ -51,6 +51,27 @@ __device__ __forceinline__ unsigned pack4(unsigned b0, unsigned b1, unsigned b2,
   return (b0 & 0xffu) | ((b1 & 0xffu) << 8) | ((b2 & 0xffu) << 16) | (b3 << 24);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it
+// waits for every outstanding global store and prefetch load at each phase boundary.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// cross-lane exchanges on the VALU (no LDS round trip)
+__device__ __forceinline__ int xor1_i(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ int xor2_i(int v) { return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true); }   // quad_perm [2,3,0,1]
+__device__ __forceinline__ float xor1_f(float v) { return __int_as_float(xor1_i(__float_as_int(v))); }
+__device__ __forceinline__ float xor2_f(float v) { return __int_as_float(xor2_i(__float_as_int(v))); }
+// value of lane ^ 16 / lane ^ 32
+__device__ __forceinline__ int xor16_i(int v) {
+  const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+  return (int)(((threadIdx.x >> 4) & 1) ? r[0] : r[1]);
+}
+__device__ __forceinline__ int xor32_i(int v) {
+  const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+  return (int)(((threadIdx.x >> 5) & 1) ? r[0] : r[1]);
+}
+
 // exp with a fixed arithmetic, identical to oracle/ita_oracle.c:ita_oracle_expf
 __device__ __forceinline__ float ita_expf(float x) {
   x = fminf(fmaxf(x, -87.0f), 88.0f);
@@ -84,8 +105,8 @@ __device__ __forceinline__ void layernorm_lanes(float (&r)[E / NT], const float*
     float p = 0.0f;
 #pragma unroll
     for (int i = 0; i < EC; ++i) p = p + r[i];
-    float s1 = p + __shfl_xor(p, 1);
-    tot = s1 + __shfl_xor(s1, 2);
+    float s1 = p + xor1_f(p);
+    tot = s1 + xor2_f(s1);
   } else {
     float pa = 0.0f, pb = 0.0f;
 #pragma unroll
@@ -93,15 +114,15 @@ __device__ __forceinline__ void layernorm_lanes(float (&r)[E / NT], const float*
 #pragma unroll
     for (int i = 0; i < Q; ++i) pb = pb + r[Q + i];
     float s1 = pa + pb;
-    tot = s1 + __shfl_xor(s1, 1);
+    tot = s1 + xor1_f(s1);
   }
   const float mean = tot * inv_e;
   if constexpr (NT == 4) {
     float p = 0.0f;
 #pragma unroll
     for (int i = 0; i < EC; ++i) { float d = r[i] - mean; p = fmaf(d, d, p); }
-    float s1 = p + __shfl_xor(p, 1);
-    tot = s1 + __shfl_xor(s1, 2);
+    float s1 = p + xor1_f(p);
+    tot = s1 + xor2_f(s1);
   } else {
     float pa = 0.0f, pb = 0.0f;
 #pragma unroll
@@ -109,7 +130,7 @@ __device__ __forceinline__ void layernorm_lanes(float (&r)[E / NT], const float*
 #pragma unroll
     for (int i = 0; i < Q; ++i) { float d = r[Q + i] - mean; pb = fmaf(d, d, pb); }
     float s1 = pa + pb;
-    tot = s1 + __shfl_xor(s1, 1);
+    tot = s1 + xor1_f(s1);
   }
   const float var = tot * inv_e;
   const float rstd = 1.0f / sqrtf(var + 1e-5f);

@@ -30,6 +30,9 @@ struct ItaEncArgs {
   float f_inv_sx, m1, m2, s2;                    // FFN scalars
   const float *n1w, *n1b, *n2w, *n2b;
   int B;
+  // diagnostic only (null in production): wave 0 of each workgroup stores s_memtime at the 10 phase
+  // boundaries of its first 8 frames: stamps[(block * 8 + frame) * 10 + phase]
+  unsigned long long* stamps;
 };
 
 struct ItaEncLds {
@@ -50,12 +53,22 @@ struct ItaEncLds {
 static_assert(ItaEncLds::H + 128 * 256 <= ItaEncLds::COLSUM, "FFN hidden layer must fit in the K + V^T region");
 static_assert(ItaEncLds::TOTAL <= 160 * 1024, "LDS budget");
 
-// weights [rows][K] row-major in global -> chunk-major LDS image
-template <int KB>
-__device__ __forceinline__ void load_weight_cm(const int8_t* __restrict__ w, int rows, char* dst, int tid) {
-  for (int p = tid; p < rows * (KB / 16); p += 512) {
-    const int row = p / (KB / 16), ch = p - row * (KB / 16);
-    *(i32x4*)(dst + ((ch * rows + row) << 4)) = *(const i32x4*)(w + (size_t)row * KB + 16 * ch);
+// weights [ROWS][KB] row-major in global -> chunk-major LDS image.  All loads are issued before
+// the first LDS store so that the memory latency is paid once, not once per piece.
+template <int KB, int ROWS>
+__device__ __forceinline__ void load_weight_cm(const int8_t* __restrict__ w, char* dst, int tid) {
+  constexpr int CH = KB / 16, NP = ROWS * CH, N = (NP + 511) / 512;
+  i32x4 v[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const int p = tid + 512 * j;
+    v[j] = (i32x4){0, 0, 0, 0};
+    if (p < NP) v[j] = *(const i32x4*)(w + (size_t)p * 16);
+  }
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const int p = tid + 512 * j, row = p / CH, ch = p - row * CH;
+    if (p < NP) *(i32x4*)(dst + ((ch * ROWS + row) << 4)) = v[j];
   }
 }
 
@@ -111,10 +124,10 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
             *l_b2 = bias + 3 * P + E + F;
 
   // ---- once per workgroup: weights and biases
-  load_weight_cm<E>(a.wq, P, lds + L::WQ, tid);
-  load_weight_cm<E>(a.wk, P, lds + L::WK, tid);
-  load_weight_cm<E>(a.wv, P, lds + L::WV, tid);
-  load_weight_cm<E>(a.w1, F, lds + L::W1, tid);
+  load_weight_cm<E, P>(a.wq, lds + L::WQ, tid);
+  load_weight_cm<E, P>(a.wk, lds + L::WK, tid);
+  load_weight_cm<E, P>(a.wv, lds + L::WV, tid);
+  load_weight_cm<E, F>(a.w1, lds + L::W1, tid);
   for (int i = tid; i < 3 * P + E + F + E; i += 512) {
     int v;
     if (i < P) v = a.bq[i];
@@ -143,7 +156,13 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
     }
   }
 
-  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+  int fi = 0;
+#define ITA_STAMP(ph)                                                                                   \
+  do {                                                                                                  \
+    if (a.stamps && tid == 0 && fi < 8) a.stamps[((size_t)blockIdx.x * 8 + fi) * 10 + (ph)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x, ++fi) {
+    ITA_STAMP(0);
     // ---------------- phase 0: quantise (xr holds this thread's 16 channels of one token)
     {
       i32x4 pk;
@@ -154,7 +173,8 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
       *(i32x4*)(lds + L::XQ + cm_off(token, qtr * EC, 128)) = pk;
     }
     if (tid < P) colsum[tid] = 0;
-    __syncthreads();
+    lds_barrier();
+    ITA_STAMP(1);
 
     // ---------------- phase P: Q, K, V projections
     {
@@ -187,12 +207,13 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
             const int kb = tt >> 1, kq = 2 * (g & 1) + h, t = 2 * (tt & 1) + (g >> 1);
             *(unsigned*)(lds + L::VT + (((kb * 4 + kq) * P + d) << 4) + 4 * t) = pack4(b0, b1, b2, b3);
           }
-          csum += __shfl_xor(csum, 32);
+          csum += xor32_i(csum);
           if (h == 0) atomicAdd(&colsum[d], csum);
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
+    ITA_STAMP(2);
 
     // prefetch the next frame's tokens; they are consumed at the next phase 0
     float xn[EC];
@@ -229,16 +250,16 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
       int m = v[0];
 #pragma unroll
       for (int j = 1; j < 32; ++j) m = max(m, v[j]);
-      m = max(m, __shfl_xor(m, 16));
-      m = max(m, __shfl_xor(m, 32));
+      m = max(m, xor16_i(m));
+      m = max(m, xor32_i(m));
       int sum = 0;
 #pragma unroll
       for (int j = 0; j < 32; ++j) {
         v[j] = min(m - v[j], 23);
         sum += 256 >> v[j];
       }
-      sum += __shfl_xor(sum, 16);
-      sum += __shfl_xor(sum, 32);
+      sum += xor16_i(sum);
+      sum += xor32_i(sum);
       sum = max(sum, 1);
       const int inv_hi = ((int)floorf((1.0f / (float)sum) * 16711680.0f)) >> 8;
       i32x4 pf[2];
@@ -263,14 +284,16 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
             pack4(rq_bits(acc[0], a.mc), rq_bits(acc[1], a.mc), rq_bits(acc[2], a.mc), rq_bits(acc[3], a.mc));
       }
     }
-    __syncthreads();
+    lds_barrier();
+    ITA_STAMP(3);
 
     // ---------------- phase O: out_proj, weights in registers -> out_q (chunk-major, over x_q)
     {
       const i32x16 acc = tile_wreg_x<6>(wo_f, l_bo, et * 32, lds + L::Q, tt * 32, lane);
       store_tile_fx<true>(acc, a.mo, -128.0f, lds + L::XQ, 0, et * 32, tt * 32, lane, nullptr, 0);
     }
-    __syncthreads();
+    lds_barrier();
+    ITA_STAMP(4);
 
     // ---------------- phase L1: x1 = LN1(x + dequant(out_q)); quantise x1 for the FFN in place
     float x1[EC];
@@ -294,21 +317,24 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
                            q_bits(x1[4 * j + 2], a.f_inv_sx), q_bits(x1[4 * j + 3], a.f_inv_sx));
       *(i32x4*)(lds + L::XQ + cm_off(token, qtr * EC, 128)) = q4;   // same 16 bytes this thread just read
     }
-    __syncthreads();
+    lds_barrier();
+    ITA_STAMP(5);
 
     // ---------------- phase F1: fc1 + ReLU -> hidden (chunk-major over the dead K / V^T images)
     for (int ft = (wave >> 2) * 4; ft < (wave >> 2) * 4 + 4; ++ft) {
       const i32x16 acc = tile_wlds_x<E, F>(lds + L::W1, ft * 32, l_b1, lds + L::XQ, tt * 32, lane);
       store_tile_fx<true>(acc, a.m1, 0.0f, lds + L::H, 0, ft * 32, tt * 32, lane, nullptr, 0);
     }
-    __syncthreads();
+    lds_barrier();
+    ITA_STAMP(6);
 
     // ---------------- phase F2: fc2, weights in registers -> out_q (over the FFN's x_q)
     {
       const i32x16 acc = tile_wreg_x<8>(w2_f, l_b2, et * 32, lds + L::H, tt * 32, lane);
       store_tile_fx<true>(acc, a.m2, -128.0f, lds + L::XQ, 0, et * 32, tt * 32, lane, nullptr, 0);
     }
-    __syncthreads();
+    lds_barrier();
+    ITA_STAMP(7);
 
     // ---------------- phase L2: y = LN2(x1 + dequant(out_q))
     {
@@ -341,6 +367,7 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
         }
       }
     }
+    ITA_STAMP(8);
 #pragma unroll
     for (int i = 0; i < EC; ++i) xr[i] = xn[i];
     // phase 0 of the next frame writes x_q, which phase L2 above has just read: the read and the

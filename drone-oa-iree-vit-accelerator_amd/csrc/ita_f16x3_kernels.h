@@ -43,17 +43,18 @@ struct ItaGemmSplitArgs {
 // 16-byte chunks of a row XOR-swizzled with (row>>1)&7 so that the 32x32x16 fragment reads
 // (lane -> row, fixed chunk) are bank-conflict free.  Tiles are filled by LDS-DMA
 // (global_load_lds_dwordx4): LDS destination lane-linear, swizzle applied to the SOURCE chunk.
-template <int ROWS>
+template <int ROWS, int NT>
 __device__ __forceinline__ void stage_plane(const _Float16* __restrict__ g, int ld, int row0, int max_row, int k0,
                                             char* lds_plane, int tid) {
+  static_assert(ROWS * 8 % NT == 0, "pieces must divide evenly over the workgroup");
 #pragma unroll
-  for (int p = 0; p < ROWS * 8 / 256; ++p) {
-    const int piece = p * 256 + tid;            // 16-byte piece index = LDS slot (lane-linear per wave)
+  for (int p = 0; p < ROWS * 8 / NT; ++p) {
+    const int piece = p * NT + tid;             // 16-byte piece index = LDS slot (lane-linear per wave)
     const int r = piece >> 3, s = piece & 7;
     const int c = s ^ ((r >> 1) & 7);
     const int gr = min(row0 + r, max_row);
     const _Float16* src = g + (size_t)gr * ld + k0 + c * 8;
-    char* dst = lds_plane + (p * 256 + (tid & ~63)) * 16;   // wave-uniform base; HW adds lane*16
+    char* dst = lds_plane + (p * NT + (tid & ~63)) * 16;    // wave-uniform base; HW adds lane*16
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   }
@@ -70,15 +71,24 @@ struct ItaGemmSplitLds {
   static constexpr int TOTAL = 2 * BUF;
 };
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void ita_gemm_f16x3_kernel(const ItaGemmSplitArgs g) {
+// WM x WN waves; each wave owns a (BM/WM) x (BN/WN) block of 32x32 MFMA tiles.  Two waves per SIMD
+// (WM*WN = 8) let one wave's MFMAs run while its partner waits for the LDS-DMA of the next K tile.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void ita_gemm_f16x3_kernel(const ItaGemmSplitArgs g) {
   using L = ItaGemmSplitLds<BM, BN>;
-  constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave per dim (waves 2 x 2)
+  constexpr int NT = 64 * WM * WN;
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);   // 32x32 MFMA tiles per wave per dim
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int kslice = g.K / g.nsplit, kbeg = blockIdx.z * kslice;
+  const int wm = wave / WN, wn = wave % WN;
+  // 1-D grid, XCD-aware: consecutive workgroup ids are dealt round-robin over the 8 XCDs, so
+  // id % nsplit picks the K slice -> with nsplit = 8 every XCD works on ONE K slice and its private
+  // L2 holds that slice of A and W (6 MB) instead of seeing all 50 MB.  Placement only affects speed.
+  const int bid = blockIdx.x;
+  const int zsplit = bid % g.nsplit, tile = bid / g.nsplit;
+  const int ntn = g.N / BN;
+  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+  const int kslice = g.K / g.nsplit, kbeg = zsplit * kslice;
   const int nt = kslice / 64;
   const int r = lane & 31, h = lane >> 5;
 
@@ -93,10 +103,10 @@ __global__ __launch_bounds__(256) void ita_gemm_f16x3_kernel(const ItaGemmSplitA
   auto stage = [&](int buf, int t) {
     char* b = lds + buf * L::BUF;
     const int k0 = kbeg + t * 64;
-    stage_plane<BM>(g.a_hi, g.lda, m0, g.M - 1, k0, b, tid);
-    stage_plane<BM>(g.a_lo, g.lda, m0, g.M - 1, k0, b + L::A_PLANE, tid);
-    stage_plane<BN>(g.w_hi, g.ldw, n0, g.N - 1, k0, b + 2 * L::A_PLANE, tid);
-    stage_plane<BN>(g.w_lo, g.ldw, n0, g.N - 1, k0, b + 2 * L::A_PLANE + L::W_PLANE, tid);
+    stage_plane<BM, NT>(g.a_hi, g.lda, m0, g.M - 1, k0, b, tid);
+    stage_plane<BM, NT>(g.a_lo, g.lda, m0, g.M - 1, k0, b + L::A_PLANE, tid);
+    stage_plane<BN, NT>(g.w_hi, g.ldw, n0, g.N - 1, k0, b + 2 * L::A_PLANE, tid);
+    stage_plane<BN, NT>(g.w_lo, g.ldw, n0, g.N - 1, k0, b + 2 * L::A_PLANE + L::W_PLANE, tid);
   };
 
   stage(0, 0);
@@ -111,13 +121,13 @@ __global__ __launch_bounds__(256) void ita_gemm_f16x3_kernel(const ItaGemmSplitA
       f16x8 fah[TM], fal[TM], fwh[TN], fwl[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const int row = wm * (BM / 2) + i * 32 + r;
+        const int row = wm * (BM / WM) + i * 32 + r;
         fah[i] = frag_f16(ah, row, 2 * ks + h);
         fal[i] = frag_f16(al, row, 2 * ks + h);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int row = wn * (BN / 2) + j * 32 + r;
+        const int row = wn * (BN / WN) + j * 32 + r;
         fwh[j] = frag_f16(wh, row, 2 * ks + h);
         fwl[j] = frag_f16(wl, row, 2 * ks + h);
       }
@@ -134,15 +144,15 @@ __global__ __launch_bounds__(256) void ita_gemm_f16x3_kernel(const ItaGemmSplitA
     cur ^= 1;
   }
   // C layout: col n = lane&31, row m = (e&3) + 8*(e>>2) + 4*h
-  float* out = g.out + (size_t)blockIdx.z * g.M * g.N;
+  float* out = g.out + (size_t)zsplit * g.M * g.N;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * (BN / 2) + j * 32 + r;
+      const int n = n0 + wn * (BN / WN) + j * 32 + r;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int m = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (m < g.M) out[(size_t)m * g.N + n] = acc[i][j][e];
       }
     }
@@ -180,49 +190,95 @@ __global__ void ita_dec_finish_kernel(const ItaDecFinishArgs a) {
   }
 }
 
-// ------------------------------------------------------------------ LSTM cell (+ next input, + fc)
-struct ItaLstmCellArgs {
-  const float* gates;     // [B][512] raw accumulators (i,f,g,o)
+// ------------------------------------------------------------------ one LSTM layer per launch
+// gates = [x | h] . [W_ih | W_hh]^T on split-precision f16 MFMA, fused with the cell update
+// (nn.LSTM, seq_len 1, gate order i,f,g,o; reference QAT/model.py:84,128-129).
+// The 512 weight rows are permuted at load time to  r' = ut*32 + gate*8 + u  (ut = unit tile of 8
+// hidden units): one 32x32 MFMA tile then holds i,f,g,o of 8 units x 32 frames, and the C layout
+// (row = (e&3) + 8*(e>>2) + 4*h) puts all four gates of a (frame, unit) pair in ONE lane:
+// e>>2 is the gate, (e&3) + 4*h the unit -- the cell update needs no cross-lane traffic.
+// Workgroup = 4 waves = 128 frames x 8 units; grid (16, ceil(B/128)).
+struct ItaLstmLayerArgs {
+  const _Float16 *a_hi, *a_lo; int lda;   // [B][K] input planes  [x | h_in]
+  const _Float16 *w_hi, *w_lo; int ldw;   // [512][K] permuted rows, pre-scaled
   float inv_wscale;
-  const float* bsum;      // [512] b_ih + b_hh
+  const float* bsum;      // [512] b_ih + b_hh, original gate-major order
   const float* c_in;      // (B,128)
   float *h_out, *c_out;   // (B,128)
-  // next layer's input planes [B][256] = [h_out | next layer's h_in]; null for the last layer
-  _Float16 *nx_hi, *nx_lo;
-  const float* nx_h_in;   // (B,128)
-  // last layer only: fc 128 -> 3 (exact ascending-k fmaf chain like the oracle)
-  const float *fc_w, *fc_b;
-  float* vel;
-  int B;
+  _Float16 *nx_hi, *nx_lo;   // next layer's planes [B][256] = [h_out | next h_in], or null
+  const float* nx_h_in;      // (B,128)
+  int B, K;               // K % 64 == 0
 };
-__global__ __launch_bounds__(128) void ita_lstm_cell_kernel(const ItaLstmCellArgs a) {
-  __shared__ float hs[128];
-  const int b = blockIdx.x, j = threadIdx.x;
-  const float* g = a.gates + (size_t)b * 512;
-  const float gi = g[j] * a.inv_wscale + a.bsum[j], gf = g[128 + j] * a.inv_wscale + a.bsum[128 + j],
-              gg = g[256 + j] * a.inv_wscale + a.bsum[256 + j], go = g[384 + j] * a.inv_wscale + a.bsum[384 + j];
-  const float ig = ita_sigmoid(gi), fg = ita_sigmoid(gf), cg = ita_tanh(gg), og = ita_sigmoid(go);
-  const float c = fmaf(fg, a.c_in[(size_t)b * 128 + j], ig * cg);
-  const float hh = og * ita_tanh(c);
-  a.c_out[(size_t)b * 128 + j] = c;
-  a.h_out[(size_t)b * 128 + j] = hh;
-  if (a.nx_hi) {
-    _Float16 hi, lo;
-    split_f16(hh, hi, lo);
-    a.nx_hi[(size_t)b * 256 + j] = hi;
-    a.nx_lo[(size_t)b * 256 + j] = lo;
-    split_f16(a.nx_h_in[(size_t)b * 128 + j], hi, lo);
-    a.nx_hi[(size_t)b * 256 + 128 + j] = hi;
-    a.nx_lo[(size_t)b * 256 + 128 + j] = lo;
-  }
-  if (a.vel) {
-    hs[j] = hh;
-    __syncthreads();
-    if (j < 3) {
-      float acc = a.fc_b[j];
-      for (int k = 0; k < 128; ++k) acc = fmaf(hs[k], a.fc_w[j * 128 + k], acc);
-      a.vel[(size_t)b * 3 + j] = acc;
+struct ItaLstmLayerLds {
+  static constexpr int W_PLANE = 32 * 128, A_PLANE = 128 * 128;
+  static constexpr int BUF = 2 * W_PLANE + 2 * A_PLANE;
+  static constexpr int TOTAL = 2 * BUF;
+};
+__global__ __launch_bounds__(256) void ita_lstm_layer_kernel(const ItaLstmLayerArgs a) {
+  using L = ItaLstmLayerLds;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ut = blockIdx.x, f0 = blockIdx.y * 128;
+  const int r = lane & 31, h = lane >> 5;
+  const int nt = a.K / 64;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+  auto stage = [&](int buf, int t) {
+    char* b = lds + buf * L::BUF;
+    stage_plane<32, 256>(a.w_hi, a.ldw, ut * 32, 511, t * 64, b, tid);
+    stage_plane<32, 256>(a.w_lo, a.ldw, ut * 32, 511, t * 64, b + L::W_PLANE, tid);
+    stage_plane<128, 256>(a.a_hi, a.lda, f0, a.B - 1, t * 64, b + 2 * L::W_PLANE, tid);
+    stage_plane<128, 256>(a.a_lo, a.lda, f0, a.B - 1, t * 64, b + 2 * L::W_PLANE + L::A_PLANE, tid);
+  };
+  stage(0, 0);
+  __syncthreads();
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) stage(cur ^ 1, t + 1);
+    const char* b = lds + cur * L::BUF;
+    const char *wh = b, *wl = b + L::W_PLANE, *ah = b + 2 * L::W_PLANE, *al = ah + L::A_PLANE;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const f16x8 fwh = frag_f16(wh, r, 2 * ks + h), fwl = frag_f16(wl, r, 2 * ks + h);
+      const f16x8 fah = frag_f16(ah, wave * 32 + r, 2 * ks + h), fal = frag_f16(al, wave * 32 + r, 2 * ks + h);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwl, fah, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh, fal, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh, fah, acc, 0, 0, 0);
     }
+    __syncthreads();
+    cur ^= 1;
+  }
+  const int b = f0 + wave * 32 + r;
+  if (b >= a.B) return;
+  const int u0 = ut * 8 + 4 * h;
+  const f32x4 ci = *(const f32x4*)(a.c_in + (size_t)b * 128 + u0);
+  f32x4 hn, cn;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int u = u0 + q;
+    const float gi = acc[q] * a.inv_wscale + a.bsum[u], gf = acc[4 + q] * a.inv_wscale + a.bsum[128 + u],
+                gg = acc[8 + q] * a.inv_wscale + a.bsum[256 + u], go = acc[12 + q] * a.inv_wscale + a.bsum[384 + u];
+    const float ig = ita_sigmoid(gi), fg = ita_sigmoid(gf), cg = ita_tanh(gg), og = ita_sigmoid(go);
+    const float c = fmaf(fg, ci[q], ig * cg);
+    cn[q] = c;
+    hn[q] = og * ita_tanh(c);
+  }
+  *(f32x4*)(a.c_out + (size_t)b * 128 + u0) = cn;
+  *(f32x4*)(a.h_out + (size_t)b * 128 + u0) = hn;
+  if (a.nx_hi) {
+    const f32x4 nh = *(const f32x4*)(a.nx_h_in + (size_t)b * 128 + u0);
+    f16x4 h_hi, h_lo, n_hi, n_lo;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      _Float16 x, y;
+      split_f16(hn[q], x, y); h_hi[q] = x; h_lo[q] = y;
+      split_f16(nh[q], x, y); n_hi[q] = x; n_lo[q] = y;
+    }
+    *(f16x4*)(a.nx_hi + (size_t)b * 256 + u0) = h_hi;
+    *(f16x4*)(a.nx_lo + (size_t)b * 256 + u0) = h_lo;
+    *(f16x4*)(a.nx_hi + (size_t)b * 256 + 128 + u0) = n_hi;
+    *(f16x4*)(a.nx_lo + (size_t)b * 256 + 128 + u0) = n_lo;
   }
 }
 

@@ -16,10 +16,12 @@
 #pragma once
 #include "ita_device.h"
 
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+
 // ------------------------------------------------------------------ tokenizer
 struct ItaTokArgs {
   const void* img;    // (B,60,90) f32, or u8 wire frames
-  const float* cw;    // [E][49]
+  const float* cw;    // [50][E]: conv weights k-major, row 49 zero (prepared by ita_load_weights)
   const float* cb;    // [E]
   const float *ln_w, *ln_b;
   float* tokens;      // (B,128,E)
@@ -36,73 +38,164 @@ __device__ __forceinline__ void bilinear_src_dev(int dst, float scale, int in, i
   l1 = src - (float)i;
 }
 
+// Layout of one workgroup (256 threads = 4 waves, wave w owns tokens 32w..32w+31):
+//   img  [66][96] f32   frame with zero border                                  (all waves)
+//   wt   [50][E]  f32   conv weights k-major, row 49 = 0                         (all waves)
+//   per wave: pb [32][51] blended 7x7 patches (col 49 = 0), later overwritten by the
+//             32 x E pre-LayerNorm tokens of the same wave.
+// The 49-long dot products run on v_mfma_f32_32x32x2_f32, which on gfx950 is exactly the
+// chain  acc = fma(a_k1, b_k1, fma(a_k0, b_k0, acc))  in ascending k -- the oracle's order.
+template <int E>
+struct ItaTokLds {
+  static constexpr int PH = 66, PW = 96, PBS = 51;
+  static constexpr int IMG = 0;
+  static constexpr int WT = IMG + PH * PW * 4;
+  static constexpr int WAVE0 = WT + 50 * E * 4;
+  static constexpr int WAVE_BYTES = 32 * E * 4 > 32 * PBS * 4 ? 32 * E * 4 : 32 * PBS * 4;
+  static constexpr int TOTAL = WAVE0 + 4 * WAVE_BYTES;
+};
+
 template <int E, bool U8>
 __global__ __launch_bounds__(256) void ita_tokenizer_kernel(const ItaTokArgs a) {
-  constexpr int PH = 66, PW = 96;        // 60x90 frame with a 3-pixel zero border (+3 right for the tap shift)
-  constexpr int EC = E / 2;
+  using L = ItaTokLds<E>;
+  constexpr int PW = L::PW, PBS = L::PBS, EC = E / 2;
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  float* img = (float*)lds;              // [PH][PW]
-  float* pb = img + PH * PW;             // [128][49] blended patches
-  float* wt = pb + 128 * 49;             // [49][E]   conv weights, k-major
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 49 * E; i += 256) {
-    const int k = i / E, c = i - k * E;
-    wt[i] = a.cw[c * 49 + k];
-  }
-  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-    __syncthreads();
-    for (int i = tid; i < PH * PW; i += 256) {
-      const int y = i / PW - 3, x = i % PW - 3;
-      float v = 0.0f;
-      if (y >= 0 && y < 60 && x >= 0 && x < 90) {
-        if constexpr (U8) v = (float)((const uint8_t*)a.img)[(size_t)b * 5400 + y * 90 + x] / 255.0f;
-        else v = ((const float*)a.img)[(size_t)b * 5400 + y * 90 + x];
-      }
-      img[i] = v;
-    }
-    __syncthreads();
-    // the four bilinear taps of the conv output are blended on the input patch (both are linear)
-    for (int i = tid; i < 128 * 49; i += 256) {
-      const int t = i / 49, k = i - t * 49;
-      const int oy = t >> 4, ox = t & 15, ky = k / 7, kx = k - 7 * ky;
-      int y0, yp, x0, xp;
-      float ly, lx;
-      bilinear_src_dev(oy, 30.0f / 8.0f, 30, y0, yp, ly);
-      bilinear_src_dev(ox, 45.0f / 16.0f, 45, x0, xp, lx);
-      const float h1 = ly, h0 = 1.0f - ly, w1 = lx, w0 = 1.0f - lx;
-      const int iy = 2 * y0 + ky, ix = 2 * x0 + kx;   // (-3 conv padding) + (3 border) = 0
-      const float va = img[iy * PW + ix], vb = img[iy * PW + ix + 2 * xp];
-      const float vc = img[(iy + 2 * yp) * PW + ix], vd = img[(iy + 2 * yp) * PW + ix + 2 * xp];
-      pb[i] = h0 * (w0 * va + w1 * vb) + h1 * (w0 * vc + w1 * vd);
-    }
-    __syncthreads();
-    const int t = tid >> 1, half = tid & 1;
-    float acc[EC];
+  float* img = (float*)(lds + L::IMG);
+  float* wt = (float*)(lds + L::WT);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* pb = (float*)(lds + L::WAVE0 + wave * L::WAVE_BYTES);   // [32][PBS], then [32][E]
+  {
+    constexpr int NW = (50 * E / 4 + 255) / 256;
+    f32x4 w4[NW];
 #pragma unroll
-    for (int c = 0; c < EC; ++c) acc[c] = a.cb[half * EC + c];
-    for (int k = 0; k < 49; ++k) {
-      const float p = pb[t * 49 + k];
-      const float* w = wt + k * E + half * EC;
+    for (int j = 0; j < NW; ++j) {
+      const int p = tid + 256 * j;
+      w4[j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+      if (p < 50 * E / 4) w4[j] = *(const f32x4*)(a.cw + 4 * p);
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int p = tid + 256 * j;
+      if (p < 50 * E / 4) *(f32x4*)(wt + 4 * p) = w4[j];
+    }
+  }
+  // this thread's blend job: token (lane>>1) of this wave, taps [25*(lane&1), ...)
+  const int tl = lane >> 1, tg = wave * 32 + tl;
+  int y0, yp, x0, xp;
+  float ly, lx;
+  bilinear_src_dev(tg >> 4, 30.0f / 8.0f, 30, y0, yp, ly);
+  bilinear_src_dev(tg & 15, 45.0f / 16.0f, 45, x0, xp, lx);
+  const float h1 = ly, h0 = 1.0f - ly, w1 = lx, w0 = 1.0f - lx;
+  const int r = lane & 31, kk = lane >> 5;
+
+  for (int i = tid; i < L::PH * PW; i += 256) img[i] = 0.0f;   // the zero border is written once
+
+  // A frame is fetched with wide loads, all issued before the first LDS store, one frame ahead of
+  // the frame being computed (a load per loop iteration would expose one memory latency each).
+  constexpr int NV = U8 ? (5400 / 16 + 255) / 256 : (1350 + 255) / 256;
+  i32x4 fv[NV];
+  auto fetch = [&](int b) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int p = tid + 256 * j;
+      fv[j] = (i32x4){0, 0, 0, 0};
+      if constexpr (U8) {
+        const uint8_t* src = (const uint8_t*)a.img + (size_t)b * 5400;
+        if (p < 337) fv[j] = *(const i32x4*)(src + 16 * p);
+        else if (p == 337) { fv[j].x = *(const int*)(src + 5392); fv[j].y = *(const int*)(src + 5396); }
+      } else {
+        const float* src = (const float*)a.img + (size_t)b * 5400;
+        if (p < 1350) fv[j] = *(const i32x4*)(src + 4 * p);
+      }
+    }
+  };
+  if ((int)blockIdx.x < a.B) fetch(blockIdx.x);
+
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    __syncthreads();   // previous frame's img fully consumed
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int p = tid + 256 * j;
+      if constexpr (U8) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int idx = 16 * p + e;
+          if (idx < 5400) {
+            const int y = idx / 90, x = idx - 90 * y;
+            img[(y + 3) * PW + x + 3] = (float)((unsigned)(fv[j][e >> 2] >> (8 * (e & 3))) & 0xffu) / 255.0f;
+          }
+        }
+      } else {
+        if (p < 1350) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int idx = 4 * p + e, y = idx / 90, x = idx - 90 * y;
+            img[(y + 3) * PW + x + 3] = __int_as_float(fv[j][e]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (b + (int)gridDim.x < a.B) fetch(b + gridDim.x);
+    // blended patches (both the conv and the bilinear resize are linear)
+    {
+      const int kbeg = (lane & 1) * 25, kend = (lane & 1) ? 50 : 25;
+      for (int k = kbeg; k < kend; ++k) {
+        float v = 0.0f;
+        if (k < 49) {
+          const int ky = k / 7, kx = k - 7 * ky;
+          const int iy = 2 * y0 + ky, ix = 2 * x0 + kx;   // (-3 conv padding) + (3 border) = 0
+          const float va = img[iy * PW + ix], vb = img[iy * PW + ix + 2 * xp];
+          const float vc = img[(iy + 2 * yp) * PW + ix], vd = img[(iy + 2 * yp) * PW + ix + 2 * xp];
+          v = h0 * (w0 * va + w1 * vb) + h1 * (w0 * vc + w1 * vd);
+        }
+        pb[tl * PBS + k] = v;
+      }
+    }
+    // (pb rows are private to this wave: wave-synchronous, no workgroup barrier needed)
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    // tokens[32 x E] = bias + pb[32 x 50] . wt[50 x E]
+    f32x16v acc[E / 32];
+#pragma unroll
+    for (int ct = 0; ct < E / 32; ++ct) {
+      const float bv = a.cb[ct * 32 + r];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[ct][e] = bv;
+    }
+#pragma unroll 5
+    for (int s = 0; s < 25; ++s) {
+      const float av = pb[r * PBS + 2 * s + kk];
+#pragma unroll
+      for (int ct = 0; ct < E / 32; ++ct)
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wt[(2 * s + kk) * E + ct * 32 + r], acc[ct], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // C layout: col = channel ct*32 + r, row = token (e&3) + 8*(e>>2) + 4*kk  -> pre[token][E] over pb
+#pragma unroll
+    for (int ct = 0; ct < E / 32; ++ct)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) pb[((e & 3) + 8 * (e >> 2) + 4 * kk) * E + ct * 32 + r] = acc[ct][e];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    {
+      const int half = lane & 1;
+      float v[EC];
 #pragma unroll
       for (int c = 0; c < EC; c += 4) {
-        const f32x4 w4 = *(const f32x4*)(w + c);
-        acc[c] = fmaf(p, w4.x, acc[c]);
-        acc[c + 1] = fmaf(p, w4.y, acc[c + 1]);
-        acc[c + 2] = fmaf(p, w4.z, acc[c + 2]);
-        acc[c + 3] = fmaf(p, w4.w, acc[c + 3]);
+        const f32x4 q = *(const f32x4*)(pb + tl * E + half * EC + c);
+        v[c] = q.x; v[c + 1] = q.y; v[c + 2] = q.z; v[c + 3] = q.w;
       }
-    }
-    layernorm_lanes<E, 2>(acc, a.ln_w, a.ln_b, half * EC);
-    float* out = a.tokens + ((size_t)b * 128 + t) * E + half * EC;
+      layernorm_lanes<E, 2>(v, a.ln_w, a.ln_b, half * EC);
+      float* out = a.tokens + ((size_t)b * 128 + tg) * E + half * EC;
 #pragma unroll
-    for (int c = 0; c < EC; c += 4) {
-      f32x4 v = {acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
-      *(f32x4*)(out + c) = v;
+      for (int c = 0; c < EC; c += 4) *(f32x4*)(out + c) = (f32x4){v[c], v[c + 1], v[c + 2], v[c + 3]};
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 template <int E>
-constexpr int ita_tok_lds_bytes() { return (66 * 96 + 128 * 49 + 49 * E) * 4; }
+constexpr int ita_tok_lds_bytes() { return ItaTokLds<E>::TOTAL; }
 
 // ------------------------------------------------------------------ fusion tail
 struct ItaTailArgs {

@@ -63,6 +63,7 @@ struct ita_context {
   const float *tail_b = nullptr, *dec_w = nullptr, *dec_b = nullptr, *fc_w = nullptr, *fc_b = nullptr;
   // derived device buffers
   float* tail_wT = nullptr;
+  float* tok_wT = nullptr;                 // [50][E] conv7x7 weights k-major, row 49 = 0
   float* wcat[3] = {nullptr, nullptr, nullptr};
   float* bsum[3] = {nullptr, nullptr, nullptr};
   // split-precision (f16 hi/lo) tail: folded tail+decoder matrix and LSTM weights, pre-scaled
@@ -115,6 +116,8 @@ const T* hptr(ita_context* c, const char* name) {
 void free_weights(ita_context* c) {
   if (c->dblob) (void)hipFree(c->dblob);
   if (c->tail_wT) (void)hipFree(c->tail_wT);
+  if (c->tok_wT) (void)hipFree(c->tok_wT);
+  c->tok_wT = nullptr;
   for (int l = 0; l < 3; ++l) {
     if (c->wcat[l]) (void)hipFree(c->wcat[l]);
     if (c->bsum[l]) (void)hipFree(c->bsum[l]);
@@ -240,7 +243,7 @@ int launch_ffn(ita_context* c, int layer, const float* x, float* y, int B, bool 
 
 // whole encoder layer in one launch (E = 64)
 int launch_encoder(ita_context* c, int layer, const float* x, float* y, _Float16* y_hi, _Float16* y_lo, float* x1_tap,
-                   int B, hipStream_t s) {
+                   int B, hipStream_t s, unsigned long long* stamps = nullptr) {
   const Layer& L = c->layers[layer];
   if (!L.n1w || !L.n2w) return fail(ITA_ERR_BAD_BLOB, "LayerNorm parameters missing from the blob");
   ItaEncArgs a{};
@@ -252,6 +255,7 @@ int launch_encoder(ita_context* c, int layer, const float* x, float* y, _Float16
   a.f_inv_sx = L.fscal[ITA_F_INV_SX]; a.m1 = L.fscal[ITA_F_M1]; a.m2 = L.fscal[ITA_F_M2]; a.s2 = L.fscal[ITA_F_S2];
   a.n1w = L.n1w; a.n1b = L.n1b; a.n2w = L.n2w; a.n2b = L.n2b;
   a.B = B;
+  a.stamps = stamps;
   const int grid = B < c->num_cus ? B : c->num_cus;
   hipLaunchKernelGGL(ita_encoder_kernel, dim3(grid), dim3(512), ItaEncLds::TOTAL, s, a);
   HIPCHK(hipGetLastError());
@@ -260,7 +264,7 @@ int launch_encoder(ita_context* c, int layer, const float* x, float* y, _Float16
 
 int launch_tokenizer(ita_context* c, const void* img, int dtype, float* tokens, int B, hipStream_t s) {
   if (!c->tok_w) return fail(ITA_ERR_BAD_BLOB, "tokenizer parameters missing from the blob");
-  ItaTokArgs a{img, c->tok_w, c->tok_b, c->tok_lw, c->tok_lb, tokens, B};
+  ItaTokArgs a{img, c->tok_wT, c->tok_b, c->tok_lw, c->tok_lb, tokens, B};
   const int grid = B < 2 * c->num_cus ? B : 2 * c->num_cus;
   const bool u8 = dtype == ITA_IMAGE_U8;
   if (c->hdr.E == 64) {
@@ -293,14 +297,14 @@ int launch_gemm(const float* A, int lda, const float* W, int ldw, const float* b
   return ITA_OK;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int WM, int WN>
 int launch_gemm_split(const _Float16* a_hi, const _Float16* a_lo, int lda, const _Float16* w_hi, const _Float16* w_lo,
                       int ldw, float* out, int M, int N, int K, int nsplit, hipStream_t s) {
   if (N % BN || K % (64 * nsplit)) return fail(ITA_ERR_UNSUPPORTED, "split gemm shape");
   ItaGemmSplitArgs g{a_hi, a_lo, lda, w_hi, w_lo, ldw, out, M, N, K, nsplit};
   constexpr int lds_bytes = ItaGemmSplitLds<BM, BN>::TOTAL;
-  auto kern = ita_gemm_f16x3_kernel<BM, BN>;
-  hipLaunchKernelGGL(kern, dim3(N / BN, (M + BM - 1) / BM, nsplit), dim3(256), lds_bytes, s, g);
+  auto kern = ita_gemm_f16x3_kernel<BM, BN, WM, WN>;
+  hipLaunchKernelGGL(kern, dim3((N / BN) * ((M + BM - 1) / BM) * nsplit), dim3(64 * WM * WN), lds_bytes, s, g);
   HIPCHK(hipGetLastError());
   return ITA_OK;
 }
@@ -417,11 +421,10 @@ int ita_create(ita_handle* out, int device_ordinal) {
   if ((rc = set_lds(ita_tail_kernel<64>, ita_tail_lds_bytes<64>()))) { delete c; return rc; }
   if ((rc = set_lds(ita_encoder_kernel, ItaEncLds::TOTAL))) { delete c; return rc; }
   {
-    auto k1 = ita_gemm_f16x3_kernel<128, 128>;
-    auto k2 = ita_gemm_f16x3_kernel<64, 64>;
-    constexpr int b1 = ItaGemmSplitLds<128, 128>::TOTAL, b2 = ItaGemmSplitLds<64, 64>::TOTAL;
+    auto k1 = ita_gemm_f16x3_kernel<128, 128, 2, 4>;
+    constexpr int b1 = ItaGemmSplitLds<128, 128>::TOTAL;
     if ((rc = set_lds(k1, b1))) { delete c; return rc; }
-    if ((rc = set_lds(k2, b2))) { delete c; return rc; }
+    if ((rc = set_lds(ita_lstm_layer_kernel, ItaLstmLayerLds::TOTAL))) { delete c; return rc; }
   }
   *out = c;
   return ITA_OK;
@@ -503,6 +506,14 @@ int ita_load_weights(ita_handle h, const void* blob, size_t nbytes) {
   h->tail_b = dptr<float>(h, "tail.conv_b", false, &ok);
   h->dec_w = dptr<float>(h, "dec.w", false, &ok); h->dec_b = dptr<float>(h, "dec.b", false, &ok);
   h->fc_w = dptr<float>(h, "fc.w", false, &ok); h->fc_b = dptr<float>(h, "fc.b", false, &ok);
+  if (const float* cw = hptr<float>(h, "tok.conv_w")) {
+    const int Ei = hdr.E;
+    std::vector<float> wT((size_t)50 * Ei, 0.0f);
+    for (int c = 0; c < Ei; ++c)
+      for (int k = 0; k < 49; ++k) wT[(size_t)k * Ei + c] = cw[(size_t)c * 49 + k];
+    HIPCHK(hipMalloc(&h->tok_wT, wT.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(h->tok_wT, wT.data(), wT.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
   // derived: conv3x3 weights re-laid [c][ky][kx][o -> 12] so one tap's 9 output weights are contiguous
   if (const float* cw = hptr<float>(h, "tail.conv_w")) {
     const int cin = hdr.E / 4 + hdr.E;
@@ -534,8 +545,12 @@ int ita_load_weights(ita_handle h, const void* blob, size_t nbytes) {
       HIPCHK(hipMemcpy(h->bsum[l], bs.data(), 512 * sizeof(float), hipMemcpyHostToDevice));
       // split-precision planes of the same concatenated matrix (layer 0 padded to K0F)
       const int kf = l == 0 ? K0F : 256;
+      // rows permuted to r' = ut*32 + gate*8 + u so that one MFMA tile holds i,f,g,o of 8 units
       std::vector<float> wf((size_t)512 * kf, 0.0f);
-      for (int j = 0; j < 512; ++j) memcpy(&wf[(size_t)j * kf], &wc[(size_t)j * kp], sizeof(float) * (in + 128));
+      for (int rp = 0; rp < 512; ++rp) {
+        const int j = ((rp >> 3) & 3) * 128 + (rp >> 5) * 8 + (rp & 7);
+        memcpy(&wf[(size_t)rp * kf], &wc[(size_t)j * kp], sizeof(float) * (in + 128));
+      }
       int rc2 = split_upload(wf, &h->lw_hi[l], &h->lw_lo[l], &h->lw_inv_scale[l]);
       if (rc2) { free_weights(h); return rc2; }
     }
@@ -594,6 +609,15 @@ int ita_encoder_layer(ita_handle h, int layer, const float* x, float* y, int bat
   if (h->hdr.E == 64) return launch_encoder(h, layer, x, y, nullptr, nullptr, nullptr, batch, (hipStream_t)stream);
   if ((rc = launch_mha(h, layer, x, y, batch, true, nullptr, (hipStream_t)stream))) return rc;
   return launch_ffn(h, layer, y, y, batch, true, nullptr, (hipStream_t)stream);
+}
+
+int ita_debug_encoder_stamps(ita_handle h, int layer, const float* x, float* y, int batch, unsigned long long* stamps,
+                             void* stream) {
+  int rc = check(h, batch);
+  if (rc) return rc;
+  if (!x || !y || !stamps || layer < 0 || layer >= h->hdr.num_layers || h->hdr.E != 64)
+    return fail(ITA_ERR_INVALID_ARG, "bad argument");
+  return launch_encoder(h, layer, x, y, nullptr, nullptr, nullptr, batch, (hipStream_t)stream, stamps);
 }
 
 int ita_tokenizer(ita_handle h, const void* image, int image_dtype, float* tokens, int batch, void* stream) {
@@ -656,7 +680,7 @@ int ita_vitlstm_forward(ita_handle h, const void* image, int image_dtype, const 
   if (taps && taps->x2) HIPCHK(hipMemcpyAsync(taps->x2, h->bufA, tokb, hipMemcpyDeviceToDevice, s));
   if (fast) {
     // folded tail+decoder: dec = x2 . Wfold^T + bias'   (x2 planes were written by the last FFN)
-    if ((rc = launch_gemm_split<128, 128>(h->x2_hi, h->x2_lo, KFOLD, h->fold_hi, h->fold_lo, KFOLD, h->part, B, 512,
+    if ((rc = launch_gemm_split<128, 128, 2, 4>(h->x2_hi, h->x2_lo, KFOLD, h->fold_hi, h->fold_lo, KFOLD, h->part, B, 512,
                                           KFOLD, NSPLIT, s))) return rc;
     MARK();
     {
@@ -670,16 +694,16 @@ int ita_vitlstm_forward(ita_handle h, const void* image, int image_dtype, const 
     _Float16* clo[3] = {h->c0_lo, h->c1_lo, h->c2_lo};
     const int kf[3] = {K0F, 256, 256};
     for (int l = 0; l < 3; ++l) {
-      if ((rc = launch_gemm_split<64, 64>(chi[l], clo[l], kf[l], h->lw_hi[l], h->lw_lo[l], kf[l], h->gates, B, 512,
-                                          kf[l], 1, s))) return rc;
-      ItaLstmCellArgs p{h->gates, h->lw_inv_scale[l], h->bsum[l], c_in + (size_t)l * B * 128,
-                        h_out + (size_t)l * B * 128, c_out + (size_t)l * B * 128,
-                        l < 2 ? chi[l + 1] : nullptr, l < 2 ? clo[l + 1] : nullptr,
-                        l < 2 ? h_in + (size_t)(l + 1) * B * 128 : nullptr,
-                        l == 2 ? h->fc_w : nullptr, l == 2 ? h->fc_b : nullptr, l == 2 ? vel : nullptr, B};
-      hipLaunchKernelGGL(ita_lstm_cell_kernel, dim3(B), dim3(128), 0, s, p);
+      ItaLstmLayerArgs p{chi[l], clo[l], kf[l], h->lw_hi[l], h->lw_lo[l], kf[l], h->lw_inv_scale[l], h->bsum[l],
+                         c_in + (size_t)l * B * 128, h_out + (size_t)l * B * 128, c_out + (size_t)l * B * 128,
+                         l < 2 ? chi[l + 1] : nullptr, l < 2 ? clo[l + 1] : nullptr,
+                         l < 2 ? h_in + (size_t)(l + 1) * B * 128 : nullptr, B, kf[l]};
+      hipLaunchKernelGGL(ita_lstm_layer_kernel, dim3(16, (B + 127) / 128), dim3(256), ItaLstmLayerLds::TOTAL, s, p);
       HIPCHK(hipGetLastError());
     }
+    hipLaunchKernelGGL(ita_fc_kernel, dim3((B * 3 + 63) / 64), dim3(64), 0, s, h_out + (size_t)2 * B * 128, h->fc_w,
+                       h->fc_b, vel, B);
+    HIPCHK(hipGetLastError());
     MARK();
   } else {
   if ((rc = launch_tail(h, h->bufA, h->feat, 4608, B, s))) return rc;

@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = (
     "ita_abi_version", "ita_create", "ita_destroy", "ita_load_weights", "ita_reserve", "ita_get_dims",
     "ita_last_error", "ita_error_string", "ita_mha_int8", "ita_mha_int8_taps", "ita_ffn_int8", "ita_ffn_int8_taps",
     "ita_encoder_layer", "ita_tokenizer", "ita_fusion_tail", "ita_vitlstm_forward", "ita_bind_dispatch",
-    "ita_profile_begin", "ita_profile_end", "ita_set_tail_mode",
+    "ita_profile_begin", "ita_profile_end", "ita_set_tail_mode", "ita_debug_encoder_stamps",
     "ITASelfAttention_workgroup", "ITASelfAttention_workgroup_expanded", "ITAFeedForward_workgroup",
 )
 
@@ -95,6 +95,7 @@ def lib():
         L.ita_vitlstm_forward.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, vp, vp, i, C.POINTER(_FwdTaps), vp]
         L.ita_bind_dispatch.argtypes = [vp, i, i]
         L.ita_set_tail_mode.argtypes = [vp, i]
+        L.ita_debug_encoder_stamps.argtypes = [vp, i, vp, vp, i, vp, vp]
         L.ita_profile_begin.argtypes = [vp, i]
         L.ita_profile_end.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i)]
         L.ITASelfAttention_workgroup.argtypes = [vp, vp]
@@ -262,6 +263,17 @@ class Engine:
         if taps:
             return vel, (h_out, c_out), tp
         return vel, (h_out, c_out)
+
+    def encoder_stamps(self, x, layer: int = 0):
+        """diagnostic: per-phase s_memtime stamps of the fused encoder kernel -> int64 [blocks, 8, 10]"""
+        torch = _torch()
+        x = _dev_f32(x)
+        y = torch.empty_like(x)
+        nb = min(x.shape[0], torch.cuda.get_device_properties(x.device).multi_processor_count)
+        st = torch.zeros((nb, 8, 10), dtype=torch.int64, device=x.device)
+        _chk(lib().ita_debug_encoder_stamps(self._h, layer, x.data_ptr(), y.data_ptr(), x.shape[0], st.data_ptr(),
+                                            _stream_ptr()))
+        return st
 
     def set_tail_mode(self, mode: int):
         """1: folded conv+decoder, f16x3 split-precision MFMA tail (default); 0: exact f32 kernels"""

@@ -122,6 +122,12 @@ int ita_set_tail_mode(ita_handle h, int mode);
 int ita_profile_begin(ita_handle h, int max_forwards);
 int ita_profile_end(ita_handle h, double* stage_ms, int* n_forwards);
 
+/* Diagnostic: one encoder layer with in-kernel s_memtime stamps (wave 0 of every workgroup, its
+ * first 8 frames, 10 phase boundaries): stamps[(block * 8 + frame) * 10 + phase], u64 device buffer
+ * of min(batch, #CUs) * 80 entries.  Not used by the product path. */
+int ita_debug_encoder_stamps(ita_handle h, int layer, const float* x_dev, float* y_dev, int batch,
+                             unsigned long long* stamps_dev, void* stream);
+
 /* ---- drop-in symbols of the reference plugin ---------------------------------------------- */
 
 /* Selects the context/layer the two `void` symbols below run, and the element type of their
