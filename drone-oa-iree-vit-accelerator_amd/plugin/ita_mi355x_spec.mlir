@@ -1,0 +1,148 @@
+// ita_mi355x_spec.mlir -- transform-dialect spec that routes the reference's marker ops to the
+// MI355X plugin.  Same contract as the reference spec
+// (samples/inference_udp_FPGA_custom_dispatch/plugin/ITA_spec.mlir): 2 storage-buffer bindings
+// (input read-only, output), 0 push constants, workgroup count (1,1,1), 64-byte aligned
+// subspans, static 1x128xE shapes.  Differences, all corrections of reference inconsistencies:
+//   * imports are RESOLVED AT RUNTIME (no `hal.import.static`, no object file): the GPU engine
+//     lives in libita_mi355x.so, the host registers an import provider (INTEGRATION.md section 2);
+//     the reference names an object `dummy_dispatch_aarch64.o` its CMake never builds
+//     (ITA_spec.mlir:18 vs plugin/CMakeLists.txt:19,48);
+//   * element type is f32 on both sides (the reference's C side says uint16, its MLIR side f32:
+//     ITA_dispatch.c:7 vs ITA_spec.mlir:30-33) -> call ita_bind_dispatch(h, layer, ITA_DISPATCH_F32);
+//   * two matchers: `neg` -> attention block, `abs` -> feed-forward block
+//     (models/ITA/export/ITA_ONNX.py:26,38; the reference only matches `neg`);
+//   * host triple x86_64 (the MI355X box), generic CPU.
+// Not exercised in this repository's tests: iree-compile is not installed in the build image.
+
+#ita_host_target = #hal.executable.target<"llvm-cpu", "embedded-elf-x86_64", {
+  cpu = "generic", data_layout = "e-m:e-p270:32:32-p271:32:32-p272:64:64-i64:64-i128:128-f80:128-n8:16:32:64-S128",
+  native_vector_size = 32 : i64, target_triple = "x86_64-unknown-unknown-eabi-elf"}>
+
+#ita_layout = #hal.pipeline.layout<constants = 0, bindings = [
+  #hal.pipeline.binding<storage_buffer, ReadOnly>,
+  #hal.pipeline.binding<storage_buffer>
+]>
+
+#ita_id = affine_map<(d0, d1, d2) -> (d0, d1, d2)>
+
+module attributes {transform.with_named_sequence} {
+
+  hal.executable private @ita_mi355x_executable {
+    hal.executable.variant public @x86_64 target(#ita_host_target) {
+      hal.executable.export public @ITASelfAttention ordinal(0) layout(#ita_layout)
+          count(%dev: !hal.device, %w: index) -> (index, index, index) {
+        %one = arith.constant 1 : index
+        hal.return %one, %one, %one : index, index, index
+      }
+      hal.executable.export public @ITAFeedForward ordinal(1) layout(#ita_layout)
+          count(%dev: !hal.device, %w: index) -> (index, index, index) {
+        %one = arith.constant 1 : index
+        hal.return %one, %one, %one : index, index, index
+      }
+      builtin.module {
+        // resolved through the runtime's executable import provider (symbol names = C ABI names)
+        func.func private @ITASelfAttention_workgroup(memref<f32>, memref<f32>) attributes {hal.import.bitcode = false}
+        func.func private @ITAFeedForward_workgroup(memref<f32>, memref<f32>) attributes {hal.import.bitcode = false}
+
+        func.func @ITASelfAttention() {
+          %c0 = arith.constant 0 : index
+          %in = hal.interface.binding.subspan layout(#ita_layout) binding(0) alignment(64) offset(%c0) : memref<1x128x128xf32>
+          %out = hal.interface.binding.subspan layout(#ita_layout) binding(1) alignment(64) offset(%c0) : memref<1x128x128xf32>
+          %in0 = memref.collapse_shape %in [] : memref<1x128x128xf32> into memref<f32>
+          %out0 = memref.collapse_shape %out [] : memref<1x128x128xf32> into memref<f32>
+          func.call @ITASelfAttention_workgroup(%in0, %out0) : (memref<f32>, memref<f32>) -> ()
+          return
+        }
+        func.func @ITAFeedForward() {
+          %c0 = arith.constant 0 : index
+          %in = hal.interface.binding.subspan layout(#ita_layout) binding(0) alignment(64) offset(%c0) : memref<1x128x128xf32>
+          %out = hal.interface.binding.subspan layout(#ita_layout) binding(1) alignment(64) offset(%c0) : memref<1x128x128xf32>
+          %in0 = memref.collapse_shape %in [] : memref<1x128x128xf32> into memref<f32>
+          %out0 = memref.collapse_shape %out [] : memref<1x128x128xf32> into memref<f32>
+          func.call @ITAFeedForward_workgroup(%in0, %out0) : (memref<f32>, memref<f32>) -> ()
+          return
+        }
+      }
+    }
+  }
+
+  util.func private @ita_call_attention(%x: tensor<1x128x128xf32>) -> tensor<1x128x128xf32> {
+    %w = arith.constant 1 : index
+    %y = flow.dispatch @ita_mi355x_executable::@x86_64::@ITASelfAttention[%w](%x)
+        : (tensor<1x128x128xf32>) -> tensor<1x128x128xf32>
+    util.return %y : tensor<1x128x128xf32>
+  }
+  util.func private @ita_call_ffn(%x: tensor<1x128x128xf32>) -> tensor<1x128x128xf32> {
+    %w = arith.constant 1 : index
+    %y = flow.dispatch @ita_mi355x_executable::@x86_64::@ITAFeedForward[%w](%x)
+        : (tensor<1x128x128xf32>) -> tensor<1x128x128xf32>
+    util.return %y : tensor<1x128x128xf32>
+  }
+
+  // marker `torch.neg` (attention block placeholder in the exported graph)
+  transform.named_sequence @match_neg(%root: !transform.any_op {transform.readonly})
+      -> (!transform.any_value, !transform.any_value) {
+    %ins, %outs = transform.iree.match.cast_compatible_dag_from_root %root {
+      ^bb0(%x: tensor<1x128x128xf32>):
+        %e = tensor.empty() {"match.operation_name_only"} : tensor<1x128x128xf32>
+        %r = linalg.generic {indexing_maps = [#ita_id, #ita_id], iterator_types = ["parallel", "parallel", "parallel"]}
+            ins(%x : tensor<1x128x128xf32>) outs(%e : tensor<1x128x128xf32>) {
+          ^bb0(%a: f32, %b: f32):
+            %n = arith.negf %a : f32
+            linalg.yield %n : f32
+        } -> tensor<1x128x128xf32>
+    } : (!transform.any_op) -> (!transform.any_value, !transform.any_value)
+    transform.yield %ins, %outs : !transform.any_value, !transform.any_value
+  }
+  // marker `torch.abs` (feed-forward block placeholder)
+  transform.named_sequence @match_abs(%root: !transform.any_op {transform.readonly})
+      -> (!transform.any_value, !transform.any_value) {
+    %ins, %outs = transform.iree.match.cast_compatible_dag_from_root %root {
+      ^bb0(%x: tensor<1x128x128xf32>):
+        %e = tensor.empty() {"match.operation_name_only"} : tensor<1x128x128xf32>
+        %r = linalg.generic {indexing_maps = [#ita_id, #ita_id], iterator_types = ["parallel", "parallel", "parallel"]}
+            ins(%x : tensor<1x128x128xf32>) outs(%e : tensor<1x128x128xf32>) {
+          ^bb0(%a: f32, %b: f32):
+            %n = math.absf %a : f32
+            linalg.yield %n : f32
+        } -> tensor<1x128x128xf32>
+    } : (!transform.any_op) -> (!transform.any_value, !transform.any_value)
+    transform.yield %ins, %outs : !transform.any_value, !transform.any_value
+  }
+
+  transform.named_sequence @use_attention(%ins: !transform.any_value {transform.readonly},
+                                          %out: !transform.any_value {transform.readonly}) {
+    %root = transform.get_defining_op %out : (!transform.any_value) -> !transform.any_op
+    %mod = transform.util.get_nearest_symbol_table %root : (!transform.any_op) -> !transform.any_op
+    %exe = transform.util.import_symbol @ita_mi355x_executable into %mod if undefined : (!transform.any_op) -> !transform.any_op
+    %fn = transform.util.import_symbol @ita_call_attention into %mod if undefined : (!transform.any_op) -> !transform.any_op
+    transform.util.cast_and_call %fn(%ins) -> %out after %root {
+      transform.type_conversion.tensor.cast_shape_dynamic_dims
+    } : (!transform.any_op, !transform.any_value, !transform.any_value, !transform.any_op) -> !transform.any_op
+    transform.yield
+  }
+  transform.named_sequence @use_ffn(%ins: !transform.any_value {transform.readonly},
+                                    %out: !transform.any_value {transform.readonly}) {
+    %root = transform.get_defining_op %out : (!transform.any_value) -> !transform.any_op
+    %mod = transform.util.get_nearest_symbol_table %root : (!transform.any_op) -> !transform.any_op
+    %exe = transform.util.import_symbol @ita_mi355x_executable into %mod if undefined : (!transform.any_op) -> !transform.any_op
+    %fn = transform.util.import_symbol @ita_call_ffn into %mod if undefined : (!transform.any_op) -> !transform.any_op
+    transform.util.cast_and_call %fn(%ins) -> %out after %root {
+      transform.type_conversion.tensor.cast_shape_dynamic_dims
+    } : (!transform.any_op, !transform.any_value, !transform.any_value, !transform.any_op) -> !transform.any_op
+    transform.yield
+  }
+
+  transform.named_sequence @__transform_main(%module: !transform.any_op) {
+    %funcs = transform.structured.match ops{["util.func"]} in %module : (!transform.any_op) -> !transform.any_op
+    transform.foreach %funcs : !transform.any_op {
+      ^bb1(%f: !transform.any_op):
+        transform.foreach_match in %f
+          @match_neg -> @use_attention,
+          @match_abs -> @use_ffn
+        : (!transform.any_op) -> (!transform.any_op)
+    }
+    transform.apply_dce to %module : !transform.any_op
+    transform.yield
+  }
+}
