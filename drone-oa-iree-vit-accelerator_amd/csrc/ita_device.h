@@ -47,6 +47,58 @@ __device__ __forceinline__ unsigned q_bits(float x, float inv_scale) {   // torc
   return __float_as_uint(f);
 }
 __device__ __forceinline__ int bits_to_int(unsigned b) { return (int)b - ITA_MAGIC_I; }
+
+// Round sixteen already-clamped floats to nearest-even integers and pack their low bytes into
+// four dwords: pk[g] byte b = rne(f[4g + b]).  The rounding is the fp32 add of 1.5*2^23 (the
+// mantissa then holds the two's-complement integer); SDWA writes the low byte of each sum straight
+// into byte b of the destination, so the add IS the pack: 16 VALU instructions for 16 bytes instead
+// of 16 adds + 20 and/shift/or.  gfx950 hazard (measured, tools/... sdwa micro test): a VALU that
+// reads a VGPR written by the immediately preceding dst_sel instruction sees stale bytes, and
+// inline asm is not padded by hipcc -- so the four destinations are interleaved (3 independent
+// instructions between two writes of one register) and the statement ends with one wait state.
+__device__ __forceinline__ void round_pack16(const float (&f)[16], unsigned (&pk)[4]) {
+  const float mg = ITA_MAGIC_F;
+  asm(
+      "v_add_f32_sdwa %0, %4, %20 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %1, %8, %20 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %2, %12, %20 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %3, %16, %20 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %0, %5, %20 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %1, %9, %20 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %2, %13, %20 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %3, %17, %20 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %0, %6, %20 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %1, %10, %20 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %2, %14, %20 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %3, %18, %20 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %0, %7, %20 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %1, %11, %20 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %2, %15, %20 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %3, %19, %20 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "s_nop 0"
+      : "=&v"(pk[0]), "=&v"(pk[1]), "=&v"(pk[2]), "=&v"(pk[3])
+      : "v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]), "v"(f[4]), "v"(f[5]), "v"(f[6]), "v"(f[7]), "v"(f[8]), "v"(f[9]),
+        "v"(f[10]), "v"(f[11]), "v"(f[12]), "v"(f[13]), "v"(f[14]), "v"(f[15]), "v"(mg));
+}
+__device__ __forceinline__ float rq_clamped(int acc, float mult, float lo) {
+  return __builtin_amdgcn_fmed3f((float)acc * mult, lo, 127.0f);
+}
+// requantise + pack a 16-accumulator fragment: pk[g] = bytes of acc[4g .. 4g+3]
+template <typename ACC>
+__device__ __forceinline__ void rq_pack16(const ACC& acc, float mult, float lo, unsigned (&pk)[4]) {
+  float f[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) f[i] = rq_clamped(acc[i], mult, lo);
+  round_pack16(f, pk);
+}
+// torch.quantize_per_tensor on sixteen floats
+__device__ __forceinline__ void q_pack16(const float* x, float inv_scale, unsigned (&pk)[4]) {
+  float f[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) f[i] = __builtin_amdgcn_fmed3f(x[i] * inv_scale, -128.0f, 127.0f);
+  round_pack16(f, pk);
+}
+
 __device__ __forceinline__ unsigned pack4(unsigned b0, unsigned b1, unsigned b2, unsigned b3) {
   return (b0 & 0xffu) | ((b1 & 0xffu) << 8) | ((b2 & 0xffu) << 16) | (b3 << 24);
 }
@@ -95,9 +147,8 @@ __device__ __forceinline__ float ita_tanh(float x) { return 1.0f - 2.0f / (ita_e
 // LayerNorm over E channels spread over NT adjacent lanes (NT = 2 or 4), each holding EC = E/NT
 // consecutive channels, in the oracle's summation order: 4 blocks of E/4 consecutive channels
 // summed sequentially, combined (p0+p1)+(p2+p3).   r[] is overwritten with the result.
-template <int E, int NT>
-__device__ __forceinline__ void layernorm_lanes(float (&r)[E / NT], const float* __restrict__ w,
-                                                const float* __restrict__ b, int c0) {
+template <int E, int NT, typename WP, typename BP>
+__device__ __forceinline__ void layernorm_lanes(float (&r)[E / NT], const WP& w, const BP& b, int c0) {
   constexpr int EC = E / NT, Q = E / 4;
   const float inv_e = 1.0f / (float)E;
   float tot;

@@ -22,7 +22,8 @@
 struct ItaEncArgs {
   const float* x;        // (B,128,64)
   float* y;              // (B,128,64) f32, may be null when planes are given
-  _Float16 *y_hi, *y_lo; // optional f16 hi/lo planes of y
+  _Float16 *y_hi, *y_lo; // optional f16 hi/lo planes of y, row stride ld_planes (>= 8192) per frame
+  int ld_planes;
   float* x1_tap;         // optional (B,128,64): LayerNorm1 output
   const int8_t *wq, *wk, *wv, *wo, *w1, *w2;
   const int32_t *bq, *bk, *bv, *bo, *b1, *b2;
@@ -48,7 +49,8 @@ struct ItaEncLds {
   static constexpr int WV = WK + P * E;
   static constexpr int W1 = WV + P * E;           // int8 [4][256][16]
   static constexpr int BIAS = W1 + F * E;         // int32: bq 192 | bk 192 | bv 192 | bo 64 | b1 256 | b2 64
-  static constexpr int TOTAL = BIAS + (3 * P + E + F + E) * 4;
+  static constexpr int LNP = BIAS + (3 * P + E + F + E) * 4;   // f32: n1w | n1b | n2w | n2b (64 each)
+  static constexpr int TOTAL = LNP + 4 * E * 4;
 };
 static_assert(ItaEncLds::H + 128 * 256 <= ItaEncLds::COLSUM, "FFN hidden layer must fit in the K + V^T region");
 static_assert(ItaEncLds::TOTAL <= 160 * 1024, "LDS budget");
@@ -138,6 +140,11 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
     else v = a.b2[i - 3 * P - E - F];
     bias[i] = v;
   }
+  float* lnp = (float*)(lds + L::LNP);
+  if (tid < 4 * E) {
+    const int which = tid >> 6, c = tid & 63;
+    lnp[tid] = which == 0 ? a.n1w[c] : which == 1 ? a.n1b[c] : which == 2 ? a.n2w[c] : a.n2b[c];
+  }
   // this wave's out_proj / fc2 output tile is the same for every frame: features et*32.., tokens tt*32..
   const int et = wave >> 2, tt = wave & 3;
   i32x4 wo_f[6], w2_f[8];
@@ -165,12 +172,9 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
     ITA_STAMP(0);
     // ---------------- phase 0: quantise (xr holds this thread's 16 channels of one token)
     {
-      i32x4 pk;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        pk[j] = (int)pack4(q_bits(xr[4 * j], a.inv_sx), q_bits(xr[4 * j + 1], a.inv_sx),
-                           q_bits(xr[4 * j + 2], a.inv_sx), q_bits(xr[4 * j + 3], a.inv_sx));
-      *(i32x4*)(lds + L::XQ + cm_off(token, qtr * EC, 128)) = pk;
+      unsigned p4[4];
+      q_pack16(xr, a.inv_sx, p4);
+      *(i32x4*)(lds + L::XQ + cm_off(token, qtr * EC, 128)) = (i32x4){(int)p4[0], (int)p4[1], (int)p4[2], (int)p4[3]};
     }
     if (tid < P) colsum[tid] = 0;
     lds_barrier();
@@ -198,15 +202,18 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
             const i32x4 wb = lds_frag(lds + L::WV, cm_off(d, 32 * ks + 16 * h, P));
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa, wb, acc, 0, 0, 0);
           }
-          int csum = 0;
+          // column sum of the requantised V codes (for the unsigned-probability offset): the sum of
+          // the 16 magic-biased bit patterns minus 16 * magic (integer arithmetic wraps harmlessly)
+          unsigned bsum = 0;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const unsigned b0 = rq_bits(acc[4 * g], a.mv), b1 = rq_bits(acc[4 * g + 1], a.mv),
                            b2 = rq_bits(acc[4 * g + 2], a.mv), b3 = rq_bits(acc[4 * g + 3], a.mv);
-            csum += bits_to_int(b0) + bits_to_int(b1) + bits_to_int(b2) + bits_to_int(b3);
+            bsum += (b0 + b1) + (b2 + b3);
             const int kb = tt >> 1, kq = 2 * (g & 1) + h, t = 2 * (tt & 1) + (g >> 1);
             *(unsigned*)(lds + L::VT + (((kb * 4 + kq) * P + d) << 4) + 4 * t) = pack4(b0, b1, b2, b3);
           }
+          int csum = (int)(bsum - 16u * (unsigned)ITA_MAGIC_I);
           csum += xor32_i(csum);
           if (h == 0) atomicAdd(&colsum[d], csum);
         }
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
           acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf, qf[ks], acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[4 * kt + i] = bits_to_int(rq_bits(acc[i], a.ml));
+        for (int i = 0; i < 4; ++i) v[4 * kt + i] = (int)rq_bits(acc[i], a.ml);   // magic-biased: order and differences are preserved
       }
       int m = v[0];
 #pragma unroll
@@ -272,16 +279,27 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
                                   inv_hi >> v[4 * kt + 3]) ^ 0x80808080u);
         }
 #pragma unroll
-      for (int dt = 0; dt < 12; ++dt) {
-        i32x4 acc = *(const i32x4*)(colsum + dt * 16 + 4 * kq);
-        acc = acc << 7;
+      for (int dg = 0; dg < 3; ++dg) {          // four 16-feature tiles at a time: 16 values per lane
+        float cf[16];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          const i32x4 vf = lds_frag(lds + L::VT, ((((kb * 4 + kq) * P) + dt * 16 + qi) << 4));
-          acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pf[kb], acc, 0, 0, 0);
+        for (int di = 0; di < 4; ++di) {
+          const int dt = 4 * dg + di;
+          i32x4 acc = *(const i32x4*)(colsum + dt * 16 + 4 * kq);
+          acc = acc << 7;
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) {
+            const i32x4 vf = lds_frag(lds + L::VT, ((((kb * 4 + kq) * P) + dt * 16 + qi) << 4));
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pf[kb], acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) cf[4 * di + i] = rq_clamped(acc[i], a.mc, -128.0f);
         }
-        *(unsigned*)(lds + L::Q + cm_off(q0 + qi, dt * 16 + 4 * kq, 128)) =
-            pack4(rq_bits(acc[0], a.mc), rq_bits(acc[1], a.mc), rq_bits(acc[2], a.mc), rq_bits(acc[3], a.mc));
+        unsigned c4[4];
+        round_pack16(cf, c4);
+        // c4[di] <-> features (4dg+di)*16 + 4*kq .. +3, query q0 + qi; the context overwrites this wave's own Q rows
+#pragma unroll
+        for (int di = 0; di < 4; ++di)
+          *(unsigned*)(lds + L::Q + cm_off(q0 + qi, (4 * dg + di) * 16 + 4 * kq, 128)) = c4[di];
       }
     }
     lds_barrier();
@@ -304,18 +322,15 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
         const int vv = (int)(int8_t)((unsigned)pk[j >> 2] >> (8 * (j & 3)));
         x1[j] = xr[j] + (float)vv * a.so;
       }
-      layernorm_lanes<E, 4>(x1, a.n1w, a.n1b, qtr * EC);
+      layernorm_lanes<E, 4>(x1, lnp, lnp + E, qtr * EC);
       if (a.x1_tap) {
         float* o = a.x1_tap + ((size_t)b * S + token) * E + qtr * EC;
 #pragma unroll
         for (int i = 0; i < EC; i += 4) *(f32x4*)(o + i) = (f32x4){x1[i], x1[i + 1], x1[i + 2], x1[i + 3]};
       }
-      i32x4 q4;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        q4[j] = (int)pack4(q_bits(x1[4 * j], a.f_inv_sx), q_bits(x1[4 * j + 1], a.f_inv_sx),
-                           q_bits(x1[4 * j + 2], a.f_inv_sx), q_bits(x1[4 * j + 3], a.f_inv_sx));
-      *(i32x4*)(lds + L::XQ + cm_off(token, qtr * EC, 128)) = q4;   // same 16 bytes this thread just read
+      unsigned p4[4];
+      q_pack16(x1, a.f_inv_sx, p4);   // written over the same 16 bytes this thread just read
+      *(i32x4*)(lds + L::XQ + cm_off(token, qtr * EC, 128)) = (i32x4){(int)p4[0], (int)p4[1], (int)p4[2], (int)p4[3]};
     }
     lds_barrier();
     ITA_STAMP(5);
@@ -345,7 +360,7 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
         const int vv = (int)(int8_t)((unsigned)pk[j >> 2] >> (8 * (j & 3)));
         y[j] = x1[j] + (float)vv * a.s2;
       }
-      layernorm_lanes<E, 4>(y, a.n2w, a.n2b, qtr * EC);
+      layernorm_lanes<E, 4>(y, lnp + 2 * E, lnp + 3 * E, qtr * EC);
       const size_t o = ((size_t)b * S + token) * E + qtr * EC;
       if (a.y) {
 #pragma unroll
@@ -362,8 +377,9 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
             vh[j] = hh;
             vl[j] = (_Float16)(y[i + j] - (float)hh);
           }
-          *(h8*)(a.y_hi + o + i) = vh;
-          *(h8*)(a.y_lo + o + i) = vl;
+          const size_t po = (size_t)b * a.ld_planes + token * E + qtr * EC + i;
+          *(h8*)(a.y_hi + po) = vh;
+          *(h8*)(a.y_lo + po) = vl;
         }
       }
     }

@@ -37,6 +37,7 @@ struct ItaGemmSplitArgs {
   float* out;                             // [nsplit][M][N] raw f32 accumulators
   int M, N, K;                            // K % (64 * nsplit) == 0, N % BN == 0
   int nsplit;
+  int dbg;                                // diagnostic: 1 = stage only (no MFMA), 2 = MFMA only (stage once)
 };
 
 // LDS image of one operand plane for one 64-deep K tile: row-major 128-byte rows, the eight
@@ -60,6 +61,23 @@ __device__ __forceinline__ void stage_plane(const _Float16* __restrict__ g, int 
   }
 }
 
+// register-staged alternative: the same LDS image, filled by global_load_dwordx4 -> ds_write_b128
+template <int ROWS, int NT>
+__device__ __forceinline__ void fetch_plane(const _Float16* __restrict__ g, int ld, int row0, int max_row, int k0,
+                                            i32x4 (&v)[ROWS * 8 / NT], int tid) {
+#pragma unroll
+  for (int p = 0; p < ROWS * 8 / NT; ++p) {
+    const int piece = p * NT + tid, r = piece >> 3, s = piece & 7;
+    const int c = s ^ ((r >> 1) & 7);
+    v[p] = *(const i32x4*)(g + (size_t)min(row0 + r, max_row) * ld + k0 + c * 8);
+  }
+}
+template <int ROWS, int NT>
+__device__ __forceinline__ void put_plane(char* lds_plane, const i32x4 (&v)[ROWS * 8 / NT], int tid) {
+#pragma unroll
+  for (int p = 0; p < ROWS * 8 / NT; ++p) *(i32x4*)(lds_plane + (p * NT + tid) * 16) = v[p];
+}
+
 __device__ __forceinline__ f16x8 frag_f16(const char* lds_plane, int r, int chunk) {
   return *(const f16x8*)(lds_plane + r * 128 + ((chunk ^ ((r >> 1) & 7)) << 4));
 }
@@ -73,7 +91,7 @@ struct ItaGemmSplitLds {
 
 // WM x WN waves; each wave owns a (BM/WM) x (BN/WN) block of 32x32 MFMA tiles.  Two waves per SIMD
 // (WM*WN = 8) let one wave's MFMAs run while its partner waits for the LDS-DMA of the next K tile.
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool REG = false>
 __global__ __launch_bounds__(64 * WM * WN) void ita_gemm_f16x3_kernel(const ItaGemmSplitArgs g) {
   using L = ItaGemmSplitLds<BM, BN>;
   constexpr int NT = 64 * WM * WN;
@@ -109,12 +127,8 @@ __global__ __launch_bounds__(64 * WM * WN) void ita_gemm_f16x3_kernel(const ItaG
     stage_plane<BN, NT>(g.w_lo, g.ldw, n0, g.N - 1, k0, b + 2 * L::A_PLANE + L::W_PLANE, tid);
   };
 
-  stage(0, 0);
-  __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
-  int cur = 0;
-  for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) stage(cur ^ 1, t + 1);
-    const char* b = lds + cur * L::BUF;
+  auto compute = [&](int buf) {
+    const char* b = lds + buf * L::BUF;
     const char *ah = b, *al = b + L::A_PLANE, *wh = b + 2 * L::A_PLANE, *wl = wh + L::W_PLANE;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -140,8 +154,43 @@ __global__ __launch_bounds__(64 * WM * WN) void ita_gemm_f16x3_kernel(const ItaG
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fwh[j], acc[i][j], 0, 0, 0);
         }
     }
+  };
+  int cur = 0;
+  if constexpr (!REG) {
+    stage(0, 0);
+    __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
+    for (int t = 0; t < nt; ++t) {
+      if (t + 1 < nt && g.dbg != 2) stage(cur ^ 1, t + 1);
+      if (g.dbg != 1) compute(cur);
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
+    i32x4 rah[BM * 8 / NT], ral[BM * 8 / NT], rwh[BN * 8 / NT], rwl[BN * 8 / NT];
+    auto fetch = [&](int t) {
+      const int k0 = kbeg + t * 64;
+      fetch_plane<BM, NT>(g.a_hi, g.lda, m0, g.M - 1, k0, rah, tid);
+      fetch_plane<BM, NT>(g.a_lo, g.lda, m0, g.M - 1, k0, ral, tid);
+      fetch_plane<BN, NT>(g.w_hi, g.ldw, n0, g.N - 1, k0, rwh, tid);
+      fetch_plane<BN, NT>(g.w_lo, g.ldw, n0, g.N - 1, k0, rwl, tid);
+    };
+    auto put = [&](int buf) {
+      char* b = lds + buf * L::BUF;
+      put_plane<BM, NT>(b, rah, tid);
+      put_plane<BM, NT>(b + L::A_PLANE, ral, tid);
+      put_plane<BN, NT>(b + 2 * L::A_PLANE, rwh, tid);
+      put_plane<BN, NT>(b + 2 * L::A_PLANE + L::W_PLANE, rwl, tid);
+    };
+    fetch(0);
+    put(0);
     __syncthreads();
-    cur ^= 1;
+    for (int t = 0; t < nt; ++t) {
+      if (t + 1 < nt) fetch(t + 1);          // loads in flight during the MFMAs of tile t
+      compute(cur);
+      if (t + 1 < nt) put(cur ^ 1);          // buffer cur^1 was last read in iteration t-1 (barrier below)
+      __syncthreads();
+      cur ^= 1;
+    }
   }
   // C layout: col n = lane&31, row m = (e&3) + 8*(e>>2) + 4*h
   float* out = g.out + (size_t)zsplit * g.M * g.N;
@@ -197,7 +246,6 @@ __global__ void ita_dec_finish_kernel(const ItaDecFinishArgs a) {
 // hidden units): one 32x32 MFMA tile then holds i,f,g,o of 8 units x 32 frames, and the C layout
 // (row = (e&3) + 8*(e>>2) + 4*h) puts all four gates of a (frame, unit) pair in ONE lane:
 // e>>2 is the gate, (e&3) + 4*h the unit -- the cell update needs no cross-lane traffic.
-// Workgroup = 4 waves = 128 frames x 8 units; grid (16, ceil(B/128)).
 struct ItaLstmLayerArgs {
   const _Float16 *a_hi, *a_lo; int lda;   // [B][K] input planes  [x | h_in]
   const _Float16 *w_hi, *w_lo; int ldw;   // [512][K] permuted rows, pre-scaled
@@ -209,76 +257,65 @@ struct ItaLstmLayerArgs {
   const float* nx_h_in;      // (B,128)
   int B, K;               // K % 64 == 0
 };
-struct ItaLstmLayerLds {
-  static constexpr int W_PLANE = 32 * 128, A_PLANE = 128 * 128;
-  static constexpr int BUF = 2 * W_PLANE + 2 * A_PLANE;
-  static constexpr int TOTAL = 2 * BUF;
-};
+// Workgroup = 4 waves = 32 frames x 8 units; the K dimension is split over the four waves, each
+// streaming its operand fragments straight from L2 into registers (all loads issued up front: the
+// LDS-staged version paid one memory latency per 64-deep K tile and was purely latency-bound); the
+// four partial accumulators are combined through LDS in a fixed order.  grid (16, ceil(B/32)).
+template <int NK>   // 16-deep k-steps per wave: K = 64 * NK
 __global__ __launch_bounds__(256) void ita_lstm_layer_kernel(const ItaLstmLayerArgs a) {
-  using L = ItaLstmLayerLds;
-  extern __shared__ __attribute__((aligned(16))) char lds[];
+  __shared__ float part[4][16][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ut = blockIdx.x, f0 = blockIdx.y * 128;
+  const int ut = blockIdx.x, f0 = blockIdx.y * 32;
   const int r = lane & 31, h = lane >> 5;
-  const int nt = a.K / 64;
+  const int arow = min(f0 + r, a.B - 1);
+  const size_t ao = (size_t)arow * a.lda + wave * NK * 16 + 8 * h;
+  const size_t wo = (size_t)(ut * 32 + r) * a.ldw + wave * NK * 16 + 8 * h;
+  f16x8 fah[NK], fal[NK], fwh[NK], fwl[NK];
+#pragma unroll
+  for (int s = 0; s < NK; ++s) {
+    fwh[s] = *(const f16x8*)(a.w_hi + wo + 16 * s);
+    fah[s] = *(const f16x8*)(a.a_hi + ao + 16 * s);
+    fwl[s] = *(const f16x8*)(a.w_lo + wo + 16 * s);
+    fal[s] = *(const f16x8*)(a.a_lo + ao + 16 * s);
+  }
+  __builtin_amdgcn_sched_barrier(0);   // keep every load ahead of the first MFMA (hipcc otherwise sinks them)
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-  auto stage = [&](int buf, int t) {
-    char* b = lds + buf * L::BUF;
-    stage_plane<32, 256>(a.w_hi, a.ldw, ut * 32, 511, t * 64, b, tid);
-    stage_plane<32, 256>(a.w_lo, a.ldw, ut * 32, 511, t * 64, b + L::W_PLANE, tid);
-    stage_plane<128, 256>(a.a_hi, a.lda, f0, a.B - 1, t * 64, b + 2 * L::W_PLANE, tid);
-    stage_plane<128, 256>(a.a_lo, a.lda, f0, a.B - 1, t * 64, b + 2 * L::W_PLANE + L::A_PLANE, tid);
-  };
-  stage(0, 0);
+#pragma unroll
+  for (int s = 0; s < NK; ++s) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwl[s], fah[s], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh[s], fal[s], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh[s], fah[s], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) part[wave][e][lane] = acc[e];
   __syncthreads();
-  int cur = 0;
-  for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) stage(cur ^ 1, t + 1);
-    const char* b = lds + cur * L::BUF;
-    const char *wh = b, *wl = b + L::W_PLANE, *ah = b + 2 * L::W_PLANE, *al = ah + L::A_PLANE;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const f16x8 fwh = frag_f16(wh, r, 2 * ks + h), fwl = frag_f16(wl, r, 2 * ks + h);
-      const f16x8 fah = frag_f16(ah, wave * 32 + r, 2 * ks + h), fal = frag_f16(al, wave * 32 + r, 2 * ks + h);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwl, fah, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh, fal, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh, fah, acc, 0, 0, 0);
-    }
-    __syncthreads();
-    cur ^= 1;
-  }
-  const int b = f0 + wave * 32 + r;
+  // wave q finishes unit (4h + q) of every (frame r): gates e = q, 4+q, 8+q, 12+q
+  const int q = wave, b = f0 + r;
   if (b >= a.B) return;
-  const int u0 = ut * 8 + 4 * h;
-  const f32x4 ci = *(const f32x4*)(a.c_in + (size_t)b * 128 + u0);
-  f32x4 hn, cn;
+  float gsum[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int u = u0 + q;
-    const float gi = acc[q] * a.inv_wscale + a.bsum[u], gf = acc[4 + q] * a.inv_wscale + a.bsum[128 + u],
-                gg = acc[8 + q] * a.inv_wscale + a.bsum[256 + u], go = acc[12 + q] * a.inv_wscale + a.bsum[384 + u];
-    const float ig = ita_sigmoid(gi), fg = ita_sigmoid(gf), cg = ita_tanh(gg), og = ita_sigmoid(go);
-    const float c = fmaf(fg, ci[q], ig * cg);
-    cn[q] = c;
-    hn[q] = og * ita_tanh(c);
+  for (int gte = 0; gte < 4; ++gte) {
+    const int e = 4 * gte + q;
+    gsum[gte] = ((part[0][e][lane] + part[1][e][lane]) + part[2][e][lane]) + part[3][e][lane];
   }
-  *(f32x4*)(a.c_out + (size_t)b * 128 + u0) = cn;
-  *(f32x4*)(a.h_out + (size_t)b * 128 + u0) = hn;
+  const int u = ut * 8 + 4 * h + q;
+  const float gi = gsum[0] * a.inv_wscale + a.bsum[u], gf = gsum[1] * a.inv_wscale + a.bsum[128 + u],
+              gg = gsum[2] * a.inv_wscale + a.bsum[256 + u], go = gsum[3] * a.inv_wscale + a.bsum[384 + u];
+  const float ig = ita_sigmoid(gi), fg = ita_sigmoid(gf), cg = ita_tanh(gg), og = ita_sigmoid(go);
+  const float c = fmaf(fg, a.c_in[(size_t)b * 128 + u], ig * cg);
+  const float hn = og * ita_tanh(c);
+  a.c_out[(size_t)b * 128 + u] = c;
+  a.h_out[(size_t)b * 128 + u] = hn;
   if (a.nx_hi) {
-    const f32x4 nh = *(const f32x4*)(a.nx_h_in + (size_t)b * 128 + u0);
-    f16x4 h_hi, h_lo, n_hi, n_lo;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      _Float16 x, y;
-      split_f16(hn[q], x, y); h_hi[q] = x; h_lo[q] = y;
-      split_f16(nh[q], x, y); n_hi[q] = x; n_lo[q] = y;
-    }
-    *(f16x4*)(a.nx_hi + (size_t)b * 256 + u0) = h_hi;
-    *(f16x4*)(a.nx_lo + (size_t)b * 256 + u0) = h_lo;
-    *(f16x4*)(a.nx_hi + (size_t)b * 256 + 128 + u0) = n_hi;
-    *(f16x4*)(a.nx_lo + (size_t)b * 256 + 128 + u0) = n_lo;
+    _Float16 x, y;
+    split_f16(hn, x, y);
+    a.nx_hi[(size_t)b * 256 + u] = x;
+    a.nx_lo[(size_t)b * 256 + u] = y;
+    split_f16(a.nx_h_in[(size_t)b * 128 + u], x, y);
+    a.nx_hi[(size_t)b * 256 + 128 + u] = x;
+    a.nx_lo[(size_t)b * 256 + 128 + u] = y;
   }
 }
 

@@ -26,6 +26,7 @@ struct ItaTokArgs {
   const float *ln_w, *ln_b;
   float* tokens;      // (B,128,E)
   int B;
+  int dbg;            // diagnostic bit mask: 1 skip image fill, 2 skip blend, 4 skip MFMA, 8 skip LN/store
 };
 
 __device__ __forceinline__ void bilinear_src_dev(int dst, float scale, int in, int& i0, int& ip, float& l1) {
@@ -87,6 +88,15 @@ __global__ __launch_bounds__(256) void ita_tokenizer_kernel(const ItaTokArgs a) 
   bilinear_src_dev(tg & 15, 45.0f / 16.0f, 45, x0, xp, lx);
   const float h1 = ly, h0 = 1.0f - ly, w1 = lx, w0 = 1.0f - lx;
   const int r = lane & 31, kk = lane >> 5;
+  // per-thread constants kept in registers for the whole launch: this thread's LayerNorm affine
+  // parameters (loading them per frame exposed one L2 latency per frame) ...
+  float lnw[EC], lnb[EC];
+#pragma unroll
+  for (int c = 0; c < EC; c += 4) {
+    const f32x4 w4 = *(const f32x4*)(a.ln_w + (lane & 1) * EC + c), b4 = *(const f32x4*)(a.ln_b + (lane & 1) * EC + c);
+    lnw[c] = w4.x; lnw[c + 1] = w4.y; lnw[c + 2] = w4.z; lnw[c + 3] = w4.w;
+    lnb[c] = b4.x; lnb[c + 1] = b4.y; lnb[c + 2] = b4.z; lnb[c + 3] = b4.w;
+  }
 
   for (int i = tid; i < L::PH * PW; i += 256) img[i] = 0.0f;   // the zero border is written once
 
@@ -113,6 +123,7 @@ __global__ __launch_bounds__(256) void ita_tokenizer_kernel(const ItaTokArgs a) 
 
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     __syncthreads();   // previous frame's img fully consumed
+    if (!(a.dbg & 1))
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int p = tid + 256 * j;
@@ -137,20 +148,22 @@ __global__ __launch_bounds__(256) void ita_tokenizer_kernel(const ItaTokArgs a) 
     }
     __syncthreads();
     if (b + (int)gridDim.x < a.B) fetch(b + gridDim.x);
-    // blended patches (both the conv and the bilinear resize are linear)
-    {
-      const int kbeg = (lane & 1) * 25, kend = (lane & 1) ? 50 : 25;
-      for (int k = kbeg; k < kend; ++k) {
-        float v = 0.0f;
-        if (k < 49) {
-          const int ky = k / 7, kx = k - 7 * ky;
-          const int iy = 2 * y0 + ky, ix = 2 * x0 + kx;   // (-3 conv padding) + (3 border) = 0
-          const float va = img[iy * PW + ix], vb = img[iy * PW + ix + 2 * xp];
-          const float vc = img[(iy + 2 * yp) * PW + ix], vd = img[(iy + 2 * yp) * PW + ix + 2 * xp];
-          v = h0 * (w0 * va + w1 * vb) + h1 * (w0 * vc + w1 * vd);
+    // blended patches (both the conv and the bilinear resize are linear): even lanes take kernel
+    // rows 0..3 of their token, odd lanes rows 4..6 (+ the zero pad column)
+    if (!(a.dbg & 2)) {
+      const int odd = lane & 1;
+      const int kyb = odd ? 4 : 0, kye = odd ? 7 : 4;
+      const float* p00 = img + (2 * y0) * PW + 2 * x0;   // (-3 conv padding) + (3 border) = 0
+      const int dx = 2 * xp, dy = 2 * yp * PW;
+      for (int ky = kyb; ky < kye; ++ky) {
+        const float* q = p00 + ky * PW;
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+          const float va = q[kx], vb = q[kx + dx], vc = q[kx + dy], vd = q[kx + dy + dx];
+          pb[tl * PBS + ky * 7 + kx] = h0 * (w0 * va + w1 * vb) + h1 * (w0 * vc + w1 * vd);
         }
-        pb[tl * PBS + k] = v;
       }
+      if (odd) pb[tl * PBS + 49] = 0.0f;
     }
     // (pb rows are private to this wave: wave-synchronous, no workgroup barrier needed)
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
@@ -163,6 +176,7 @@ __global__ __launch_bounds__(256) void ita_tokenizer_kernel(const ItaTokArgs a) 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[ct][e] = bv;
     }
+    if (!(a.dbg & 4))
 #pragma unroll 5
     for (int s = 0; s < 25; ++s) {
       const float av = pb[r * PBS + 2 * s + kk];
@@ -178,7 +192,7 @@ __global__ __launch_bounds__(256) void ita_tokenizer_kernel(const ItaTokArgs a) 
       for (int e = 0; e < 16; ++e) pb[((e & 3) + 8 * (e >> 2) + 4 * kk) * E + ct * 32 + r] = acc[ct][e];
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
-    {
+    if (!(a.dbg & 8)) {
       const int half = lane & 1;
       float v[EC];
 #pragma unroll
@@ -186,7 +200,7 @@ __global__ __launch_bounds__(256) void ita_tokenizer_kernel(const ItaTokArgs a) 
         const f32x4 q = *(const f32x4*)(pb + tl * E + half * EC + c);
         v[c] = q.x; v[c + 1] = q.y; v[c + 2] = q.z; v[c + 3] = q.w;
       }
-      layernorm_lanes<E, 2>(v, a.ln_w, a.ln_b, half * EC);
+      layernorm_lanes<E, 2>(v, lnw, lnb, 0);
       float* out = a.tokens + ((size_t)b * 128 + tg) * E + half * EC;
 #pragma unroll
       for (int c = 0; c < EC; c += 4) *(f32x4*)(out + c) = (f32x4){v[c], v[c + 1], v[c + 2], v[c + 3]};

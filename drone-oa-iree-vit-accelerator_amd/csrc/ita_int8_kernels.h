@@ -47,6 +47,7 @@ struct ItaFfnArgs {
   // optional second form of the output: f16 hi/lo planes [B][128*E] for the split-precision tail
   // GEMM (ita_f16x3_kernels.h); y may then be null
   _Float16 *y_hi, *y_lo;
+  int ld_planes;           // row stride (halves) of the planes per frame
 };
 
 template <int E>
@@ -86,11 +87,9 @@ __device__ __forceinline__ void quantize_tokens(const float* __restrict__ xrow, 
   }
 #pragma unroll
   for (int c = 0; c < EC; c += 16) {
-    i32x4 pk;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      pk[j] = (int)pack4(q_bits(xr[c + 4 * j], inv_sx), q_bits(xr[c + 4 * j + 1], inv_sx),
-                         q_bits(xr[c + 4 * j + 2], inv_sx), q_bits(xr[c + 4 * j + 3], inv_sx));
+    unsigned p4[4];
+    q_pack16(&xr[c], inv_sx, p4);
+    const i32x4 pk = {(int)p4[0], (int)p4[1], (int)p4[2], (int)p4[3]};
     *(i32x4*)(lds_xq + cm_off(token, qtr * EC + c, 128)) = pk;
     if (tap_row) *(i32x4*)(tap_row + qtr * EC + c) = pk;
   }
@@ -173,10 +172,11 @@ template <bool CM>
 __device__ __forceinline__ void store_tile_fx(const i32x16& acc, float mult, float lo, char* dst, int ld, int f0,
                                               int t0, int lane, int8_t* tap, int tap_ld) {
   const int r = lane & 31, h = lane >> 5;
+  unsigned p4[4];
+  rq_pack16(acc, mult, lo, p4);
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    const unsigned pk = pack4(rq_bits(acc[4 * g], mult, lo), rq_bits(acc[4 * g + 1], mult, lo),
-                              rq_bits(acc[4 * g + 2], mult, lo), rq_bits(acc[4 * g + 3], mult, lo));
+    const unsigned pk = p4[g];
     const int f = f0 + 8 * g + 4 * h;
     if constexpr (CM) *(unsigned*)(dst + cm_off(t0 + r, f, 128)) = pk;
     else *(unsigned*)(dst + (t0 + r) * ld + f) = pk;
@@ -375,7 +375,8 @@ __global__ __launch_bounds__(512) void ita_ffn_kernel(const ItaFfnArgs a) {
     }
     __syncthreads();
     const size_t o = ((size_t)b * S + token) * E + qtr * EC;
+    const size_t po = (size_t)b * a.ld_planes + token * E + qtr * EC;
     finish_tokens<E>(lds + L::OUTQ, a.s2, xr, token, qtr, a.fuse_ln != 0, a.ln_w, a.ln_b, a.y ? a.y + o : nullptr,
-                     a.y_hi ? a.y_hi + o : nullptr, a.y_lo ? a.y_lo + o : nullptr);
+                     a.y_hi ? a.y_hi + po : nullptr, a.y_lo ? a.y_lo + po : nullptr);
   }
 }

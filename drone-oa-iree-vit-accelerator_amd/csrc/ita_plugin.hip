@@ -39,6 +39,8 @@ int fail(int code, const std::string& msg) {
 constexpr int K0P = 672;    // exact-f32 path: LSTM layer-0 concat width 517 + 128 = 645, padded to a multiple of 32
 constexpr int K0F = 704;    // f16x3 path: padded to a multiple of 64
 constexpr int KFOLD = 8192; // 128 tokens x 64 channels feeding the folded tail+decoder matrix
+constexpr int LDFOLD = KFOLD + 64;   // row stride of the x2 / Wfold planes: a power-of-two stride (16 KB) would put
+                                     // every row of a K tile on the same L2 channel
 constexpr int NSPLIT = 8;   // split-K of the folded GEMM (1024 x 512 x 8192 -> 256 workgroups)
 
 struct Layer {
@@ -163,8 +165,8 @@ int ensure_workspace(ita_context* c, int B) {
   HIPCHK(hipMalloc(&c->cat1, sizeof(float) * (size_t)B * 256));
   HIPCHK(hipMalloc(&c->cat2, sizeof(float) * (size_t)B * 256));
   HIPCHK(hipMalloc(&c->gates, sizeof(float) * (size_t)B * 512));
-  HIPCHK(hipMalloc(&c->x2_hi, 2 * (size_t)B * KFOLD));
-  HIPCHK(hipMalloc(&c->x2_lo, 2 * (size_t)B * KFOLD));
+  HIPCHK(hipMalloc(&c->x2_hi, 2 * (size_t)B * LDFOLD));
+  HIPCHK(hipMalloc(&c->x2_lo, 2 * (size_t)B * LDFOLD));
   HIPCHK(hipMalloc(&c->c0_hi, 2 * (size_t)B * K0F));
   HIPCHK(hipMalloc(&c->c0_lo, 2 * (size_t)B * K0F));
   HIPCHK(hipMalloc(&c->c1_hi, 2 * (size_t)B * 256));
@@ -230,7 +232,7 @@ int launch_ffn(ita_context* c, int layer, const float* x, float* y, int B, bool 
   a.inv_sx = L.fscal[ITA_F_INV_SX]; a.m1 = L.fscal[ITA_F_M1]; a.m2 = L.fscal[ITA_F_M2]; a.s2 = L.fscal[ITA_F_S2];
   a.ln_w = L.n2w; a.ln_b = L.n2b; a.B = B; a.fuse_ln = fuse ? 1 : 0;
   if (t) { a.t_xq = t->x_q; a.t_h = t->h; a.t_out = t->out_q; }
-  a.y_hi = y_hi; a.y_lo = y_lo;
+  a.y_hi = y_hi; a.y_lo = y_lo; a.ld_planes = LDFOLD;
   const int grid = B < 2 * c->num_cus ? B : 2 * c->num_cus;
   if (c->hdr.E == 64) {
     hipLaunchKernelGGL(ita_ffn_kernel<64>, dim3(grid), dim3(512), ItaFfnLds<64>::TOTAL, s, a);
@@ -255,6 +257,7 @@ int launch_encoder(ita_context* c, int layer, const float* x, float* y, _Float16
   a.f_inv_sx = L.fscal[ITA_F_INV_SX]; a.m1 = L.fscal[ITA_F_M1]; a.m2 = L.fscal[ITA_F_M2]; a.s2 = L.fscal[ITA_F_S2];
   a.n1w = L.n1w; a.n1b = L.n1b; a.n2w = L.n2w; a.n2b = L.n2b;
   a.B = B;
+  a.ld_planes = LDFOLD;
   a.stamps = stamps;
   const int grid = B < c->num_cus ? B : c->num_cus;
   hipLaunchKernelGGL(ita_encoder_kernel, dim3(grid), dim3(512), ItaEncLds::TOTAL, s, a);
@@ -264,7 +267,8 @@ int launch_encoder(ita_context* c, int layer, const float* x, float* y, _Float16
 
 int launch_tokenizer(ita_context* c, const void* img, int dtype, float* tokens, int B, hipStream_t s) {
   if (!c->tok_w) return fail(ITA_ERR_BAD_BLOB, "tokenizer parameters missing from the blob");
-  ItaTokArgs a{img, c->tok_wT, c->tok_b, c->tok_lw, c->tok_lb, tokens, B};
+  static const int tok_dbg = getenv("ITA_TOK_DBG") ? atoi(getenv("ITA_TOK_DBG")) : 0;
+  ItaTokArgs a{img, c->tok_wT, c->tok_b, c->tok_lw, c->tok_lb, tokens, B, tok_dbg};
   const int grid = B < 2 * c->num_cus ? B : 2 * c->num_cus;
   const bool u8 = dtype == ITA_IMAGE_U8;
   if (c->hdr.E == 64) {
@@ -297,13 +301,14 @@ int launch_gemm(const float* A, int lda, const float* W, int ldw, const float* b
   return ITA_OK;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool REG = false>
 int launch_gemm_split(const _Float16* a_hi, const _Float16* a_lo, int lda, const _Float16* w_hi, const _Float16* w_lo,
                       int ldw, float* out, int M, int N, int K, int nsplit, hipStream_t s) {
   if (N % BN || K % (64 * nsplit)) return fail(ITA_ERR_UNSUPPORTED, "split gemm shape");
-  ItaGemmSplitArgs g{a_hi, a_lo, lda, w_hi, w_lo, ldw, out, M, N, K, nsplit};
+  static const int dbg = getenv("ITA_GEMM_DBG") ? atoi(getenv("ITA_GEMM_DBG")) : 0;
+  ItaGemmSplitArgs g{a_hi, a_lo, lda, w_hi, w_lo, ldw, out, M, N, K, nsplit, dbg};
   constexpr int lds_bytes = ItaGemmSplitLds<BM, BN>::TOTAL;
-  auto kern = ita_gemm_f16x3_kernel<BM, BN, WM, WN>;
+  auto kern = ita_gemm_f16x3_kernel<BM, BN, WM, WN, REG>;
   hipLaunchKernelGGL(kern, dim3((N / BN) * ((M + BM - 1) / BM) * nsplit), dim3(64 * WM * WN), lds_bytes, s, g);
   HIPCHK(hipGetLastError());
   return ITA_OK;
@@ -375,9 +380,9 @@ int build_fold(ita_context* c) {
   }
   (void)hipFree(imp); (void)hipFree(feat); (void)hipFree(mt); (void)hipFree(zero);
   if (rc) return rc;
-  std::vector<float> wf((size_t)512 * KFOLD);
+  std::vector<float> wf((size_t)512 * LDFOLD, 0.0f);
   for (int k = 0; k < KFOLD; ++k)
-    for (int j = 0; j < 512; ++j) wf[(size_t)j * KFOLD + k] = hmt[(size_t)k * 512 + j];
+    for (int j = 0; j < 512; ++j) wf[(size_t)j * LDFOLD + k] = hmt[(size_t)k * 512 + j];
   if ((rc = split_upload(wf, &c->fold_hi, &c->fold_lo, &c->fold_inv_scale))) return rc;
   HIPCHK(hipMalloc(&c->fold_bias, 512 * sizeof(float)));
   HIPCHK(hipMemcpy(c->fold_bias, hb.data(), 512 * sizeof(float), hipMemcpyHostToDevice));
@@ -422,9 +427,10 @@ int ita_create(ita_handle* out, int device_ordinal) {
   if ((rc = set_lds(ita_encoder_kernel, ItaEncLds::TOTAL))) { delete c; return rc; }
   {
     auto k1 = ita_gemm_f16x3_kernel<128, 128, 2, 4>;
+    auto k1r = ita_gemm_f16x3_kernel<128, 128, 2, 4, true>;
+    if ((rc = set_lds(k1r, ItaGemmSplitLds<128, 128>::TOTAL))) { delete c; return rc; }
     constexpr int b1 = ItaGemmSplitLds<128, 128>::TOTAL;
     if ((rc = set_lds(k1, b1))) { delete c; return rc; }
-    if ((rc = set_lds(ita_lstm_layer_kernel, ItaLstmLayerLds::TOTAL))) { delete c; return rc; }
   }
   *out = c;
   return ITA_OK;
@@ -680,8 +686,12 @@ int ita_vitlstm_forward(ita_handle h, const void* image, int image_dtype, const 
   if (taps && taps->x2) HIPCHK(hipMemcpyAsync(taps->x2, h->bufA, tokb, hipMemcpyDeviceToDevice, s));
   if (fast) {
     // folded tail+decoder: dec = x2 . Wfold^T + bias'   (x2 planes were written by the last FFN)
-    if ((rc = launch_gemm_split<128, 128, 2, 4>(h->x2_hi, h->x2_lo, KFOLD, h->fold_hi, h->fold_lo, KFOLD, h->part, B, 512,
-                                          KFOLD, NSPLIT, s))) return rc;
+    static const bool reg_stage = getenv("ITA_GEMM_REG") != nullptr;
+    if (reg_stage) {
+      if ((rc = launch_gemm_split<128, 128, 2, 4, true>(h->x2_hi, h->x2_lo, LDFOLD, h->fold_hi, h->fold_lo, LDFOLD, h->part,
+                                                        B, 512, KFOLD, NSPLIT, s))) return rc;
+    } else if ((rc = launch_gemm_split<128, 128, 2, 4>(h->x2_hi, h->x2_lo, LDFOLD, h->fold_hi, h->fold_lo, LDFOLD, h->part, B,
+                                                       512, KFOLD, NSPLIT, s))) return rc;
     MARK();
     {
       ItaDecFinishArgs d{h->part, NSPLIT, h->fold_inv_scale, h->fold_bias, desvel, quat, h_in, h->c0_hi, h->c0_lo, K0F,
@@ -698,7 +708,8 @@ int ita_vitlstm_forward(ita_handle h, const void* image, int image_dtype, const 
                          c_in + (size_t)l * B * 128, h_out + (size_t)l * B * 128, c_out + (size_t)l * B * 128,
                          l < 2 ? chi[l + 1] : nullptr, l < 2 ? clo[l + 1] : nullptr,
                          l < 2 ? h_in + (size_t)(l + 1) * B * 128 : nullptr, B, kf[l]};
-      hipLaunchKernelGGL(ita_lstm_layer_kernel, dim3(16, (B + 127) / 128), dim3(256), ItaLstmLayerLds::TOTAL, s, p);
+      if (l == 0) hipLaunchKernelGGL(ita_lstm_layer_kernel<K0F / 64>, dim3(16, (B + 31) / 32), dim3(256), 0, s, p);
+      else hipLaunchKernelGGL(ita_lstm_layer_kernel<4>, dim3(16, (B + 31) / 32), dim3(256), 0, s, p);
       HIPCHK(hipGetLastError());
     }
     hipLaunchKernelGGL(ita_fc_kernel, dim3((B * 3 + 63) / 64), dim3(64), 0, s, h_out + (size_t)2 * B * 128, h->fc_w,
