@@ -218,6 +218,7 @@ struct ItaDecFinishArgs {
   int ld;                               // 704
   float* dec_tap;                       // optional (B,512) f32
   int B;
+  const int* slots;                     // optional: state row of frame b (persistent per-stream state), else b
 };
 __global__ void ita_dec_finish_kernel(const ItaDecFinishArgs a) {
   const int b = blockIdx.x;
@@ -230,7 +231,7 @@ __global__ void ita_dec_finish_kernel(const ItaDecFinishArgs a) {
       if (a.dec_tap) a.dec_tap[(size_t)b * 512 + j] = v;
     } else if (j == 512) v = a.desvel[b] / 10.0f;
     else if (j < 517) v = a.quat[(size_t)b * 4 + j - 513];
-    else if (j < 645) v = a.h_in0[(size_t)b * 128 + j - 517];
+    else if (j < 645) v = a.h_in0[(size_t)(a.slots ? a.slots[b] : b) * 128 + j - 517];
     else v = 0.0f;
     _Float16 hi, lo;
     split_f16(v, hi, lo);
@@ -256,6 +257,7 @@ struct ItaLstmLayerArgs {
   _Float16 *nx_hi, *nx_lo;   // next layer's planes [B][256] = [h_out | next h_in], or null
   const float* nx_h_in;      // (B,128)
   int B, K;               // K % 64 == 0
+  const int* slots;       // optional: state row (c_in, h_out, c_out, nx_h_in) of frame b, else b
 };
 // Workgroup = 4 waves = 32 frames x 8 units; the K dimension is split over the four waves, each
 // streaming its operand fragments straight from L2 into registers (all loads issued up front: the
@@ -294,6 +296,7 @@ __global__ __launch_bounds__(256) void ita_lstm_layer_kernel(const ItaLstmLayerA
   // wave q finishes unit (4h + q) of every (frame r): gates e = q, 4+q, 8+q, 12+q
   const int q = wave, b = f0 + r;
   if (b >= a.B) return;
+  const size_t sb = a.slots ? (size_t)a.slots[b] : (size_t)b;
   float gsum[4];
 #pragma unroll
   for (int gte = 0; gte < 4; ++gte) {
@@ -304,16 +307,16 @@ __global__ __launch_bounds__(256) void ita_lstm_layer_kernel(const ItaLstmLayerA
   const float gi = gsum[0] * a.inv_wscale + a.bsum[u], gf = gsum[1] * a.inv_wscale + a.bsum[128 + u],
               gg = gsum[2] * a.inv_wscale + a.bsum[256 + u], go = gsum[3] * a.inv_wscale + a.bsum[384 + u];
   const float ig = ita_sigmoid(gi), fg = ita_sigmoid(gf), cg = ita_tanh(gg), og = ita_sigmoid(go);
-  const float c = fmaf(fg, a.c_in[(size_t)b * 128 + u], ig * cg);
+  const float c = fmaf(fg, a.c_in[sb * 128 + u], ig * cg);
   const float hn = og * ita_tanh(c);
-  a.c_out[(size_t)b * 128 + u] = c;
-  a.h_out[(size_t)b * 128 + u] = hn;
+  a.c_out[sb * 128 + u] = c;
+  a.h_out[sb * 128 + u] = hn;
   if (a.nx_hi) {
     _Float16 x, y;
     split_f16(hn, x, y);
     a.nx_hi[(size_t)b * 256 + u] = x;
     a.nx_lo[(size_t)b * 256 + u] = y;
-    split_f16(a.nx_h_in[(size_t)b * 128 + u], x, y);
+    split_f16(a.nx_h_in[sb * 128 + u], x, y);
     a.nx_hi[(size_t)b * 256 + 128 + u] = x;
     a.nx_lo[(size_t)b * 256 + 128 + u] = y;
   }

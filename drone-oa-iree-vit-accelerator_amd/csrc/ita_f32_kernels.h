@@ -403,11 +403,12 @@ __global__ void ita_lstm_point_kernel(const ItaLstmPointArgs a) {
 
 // fc 128 -> 3
 __global__ void ita_fc_kernel(const float* __restrict__ h, const float* __restrict__ w, const float* __restrict__ bias,
-                              float* __restrict__ vel, int B) {
+                              float* __restrict__ vel, int B, const int* __restrict__ slots = nullptr) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * 3) return;
   const int b = idx / 3, o = idx - 3 * b;
+  const size_t hb = slots ? (size_t)slots[b] : (size_t)b;
   float acc = bias[o];
-  for (int k = 0; k < 128; ++k) acc = fmaf(h[(size_t)b * 128 + k], w[o * 128 + k], acc);
+  for (int k = 0; k < 128; ++k) acc = fmaf(h[hb * 128 + k], w[o * 128 + k], acc);
   vel[idx] = acc;
 }

@@ -14,6 +14,7 @@
 
 #include "../../include/ita_mi355x.h"
 #include "../../include/ita_weights.h"
+#include "../../include/ita_wire.h"
 #include "ita_encoder_kernel.h"
 #include "ita_f16x3_kernels.h"
 #include "ita_f32_kernels.h"
@@ -641,9 +642,9 @@ int ita_fusion_tail(ita_handle h, const float* x, float* feat, int batch, void* 
   return launch_tail(h, x, feat, 4608, batch, (hipStream_t)stream);
 }
 
-int ita_vitlstm_forward(ita_handle h, const void* image, int image_dtype, const float* desvel, const float* quat,
+static int forward_impl(ita_handle h, const void* image, int image_dtype, const float* desvel, const float* quat,
                         const float* h_in, const float* c_in, float* vel, float* h_out, float* c_out, int batch,
-                        const ita_forward_taps* taps, void* stream) {
+                        const ita_forward_taps* taps, void* stream, const int* slots, int state_rows) {
   int rc = check(h, batch);
   if (rc) return rc;
   if (!image || !desvel || !quat || !h_in || !c_in || !vel || !h_out || !c_out)
@@ -656,7 +657,8 @@ int ita_vitlstm_forward(ita_handle h, const void* image, int image_dtype, const 
   const int B = batch;
   const size_t tokb = sizeof(float) * (size_t)B * 128 * h->hdr.E;
   const bool fast = h->tail_mode == 1 && h->folded;
-  if (fast && h_out == h_in) return fail(ITA_ERR_INVALID_ARG, "hidden_out_h must not alias hidden_in_h in f16x3 tail mode");
+  if (slots && !fast) return fail(ITA_ERR_UNSUPPORTED, "slot-indexed state needs tail mode 1");
+  const size_t lstride = (size_t)(slots ? state_rows : batch) * 128;   // layer stride of the (3, rows, 128) state
   const int ev_per_fwd = 5 + 2 * h->hdr.num_layers;
   hipEvent_t* ev = (h->prof && h->prof_n < h->prof_max) ? &h->prof_ev[(size_t)h->prof_n * ev_per_fwd] : nullptr;
   int evi = 0;
@@ -695,7 +697,7 @@ int ita_vitlstm_forward(ita_handle h, const void* image, int image_dtype, const 
     MARK();
     {
       ItaDecFinishArgs d{h->part, NSPLIT, h->fold_inv_scale, h->fold_bias, desvel, quat, h_in, h->c0_hi, h->c0_lo, K0F,
-                         taps ? taps->dec : nullptr, B};
+                         taps ? taps->dec : nullptr, B, slots};
       hipLaunchKernelGGL(ita_dec_finish_kernel, dim3(B), dim3(256), 0, s, d);
       HIPCHK(hipGetLastError());
     }
@@ -705,15 +707,15 @@ int ita_vitlstm_forward(ita_handle h, const void* image, int image_dtype, const 
     const int kf[3] = {K0F, 256, 256};
     for (int l = 0; l < 3; ++l) {
       ItaLstmLayerArgs p{chi[l], clo[l], kf[l], h->lw_hi[l], h->lw_lo[l], kf[l], h->lw_inv_scale[l], h->bsum[l],
-                         c_in + (size_t)l * B * 128, h_out + (size_t)l * B * 128, c_out + (size_t)l * B * 128,
+                         c_in + l * lstride, h_out + l * lstride, c_out + l * lstride,
                          l < 2 ? chi[l + 1] : nullptr, l < 2 ? clo[l + 1] : nullptr,
-                         l < 2 ? h_in + (size_t)(l + 1) * B * 128 : nullptr, B, kf[l]};
+                         l < 2 ? h_in + (l + 1) * lstride : nullptr, B, kf[l], slots};
       if (l == 0) hipLaunchKernelGGL(ita_lstm_layer_kernel<K0F / 64>, dim3(16, (B + 31) / 32), dim3(256), 0, s, p);
       else hipLaunchKernelGGL(ita_lstm_layer_kernel<4>, dim3(16, (B + 31) / 32), dim3(256), 0, s, p);
       HIPCHK(hipGetLastError());
     }
-    hipLaunchKernelGGL(ita_fc_kernel, dim3((B * 3 + 63) / 64), dim3(64), 0, s, h_out + (size_t)2 * B * 128, h->fc_w,
-                       h->fc_b, vel, B);
+    hipLaunchKernelGGL(ita_fc_kernel, dim3((B * 3 + 63) / 64), dim3(64), 0, s, h_out + 2 * lstride, h->fc_w,
+                       h->fc_b, vel, B, slots);
     HIPCHK(hipGetLastError());
     MARK();
   } else {
@@ -749,6 +751,20 @@ int ita_vitlstm_forward(ita_handle h, const void* image, int image_dtype, const 
 #undef MARK
   if (ev) ++h->prof_n;
   return ITA_OK;
+}
+
+int ita_vitlstm_forward(ita_handle h, const void* image, int image_dtype, const float* desvel, const float* quat,
+                        const float* h_in, const float* c_in, float* vel, float* h_out, float* c_out, int batch,
+                        const ita_forward_taps* taps, void* stream) {
+  return forward_impl(h, image, image_dtype, desvel, quat, h_in, c_in, vel, h_out, c_out, batch, taps, stream, nullptr, 0);
+}
+
+int ita_vitlstm_forward_slots(ita_handle h, const void* image, int image_dtype, const float* desvel, const float* quat,
+                              float* state_h, float* state_c, const int* slot_idx, int num_slots, float* vel, int batch,
+                              void* stream) {
+  if (!slot_idx || num_slots < batch) return fail(ITA_ERR_INVALID_ARG, "slot_idx null or fewer slots than frames");
+  return forward_impl(h, image, image_dtype, desvel, quat, state_h, state_c, vel, state_h, state_c, batch, nullptr, stream,
+                      slot_idx, num_slots);
 }
 
 int ita_profile_begin(ita_handle h, int max_forwards) {
@@ -795,6 +811,17 @@ int ita_profile_end(ita_handle h, double* stage_ms, int* n_forwards) {
   *n_forwards = h->prof_n;
   h->prof_n = 0;
   return ITA_OK;
+}
+
+int ita_wire_unpack_packet(const uint8_t* packet, size_t nbytes, int quat_stride_bug, float* frame_out) {
+  ita_wire_frame f;
+  if (!frame_out || ita_wire_unpack(packet, nbytes, quat_stride_bug, &f)) return fail(ITA_ERR_INVALID_ARG, "short packet");
+  frame_out[0] = f.desired_velocity; frame_out[1] = f.position_x;
+  for (int i = 0; i < 4; ++i) frame_out[2 + i] = f.quaternion[i];
+  return ITA_OK;
+}
+void ita_wire_postprocess(const float* raw3, float desired_velocity, float position_x, float* out3) {
+  ita_wire_final_velocity(raw3, desired_velocity, position_x, out3);
 }
 
 int ita_set_tail_mode(ita_handle h, int mode) {

@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = (
     "ita_last_error", "ita_error_string", "ita_mha_int8", "ita_mha_int8_taps", "ita_ffn_int8", "ita_ffn_int8_taps",
     "ita_encoder_layer", "ita_tokenizer", "ita_fusion_tail", "ita_vitlstm_forward", "ita_bind_dispatch",
     "ita_profile_begin", "ita_profile_end", "ita_set_tail_mode", "ita_debug_encoder_stamps",
+    "ita_wire_unpack_packet", "ita_wire_postprocess", "ita_vitlstm_forward_slots",
     "ITASelfAttention_workgroup", "ITASelfAttention_workgroup_expanded", "ITAFeedForward_workgroup",
 )
 
@@ -56,6 +57,22 @@ def build_extension(force: bool = False, verbose: bool = False) -> str:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     return _SO
+
+
+def build_samples(force: bool = False, verbose: bool = False) -> str:
+    """the UDP inference host (reference samples/inference_udp_FPGA_custom_dispatch/main.cpp)"""
+    src = os.path.join(_HERE, "samples", "ita_udp_server.cpp")
+    exe = os.path.join(_HERE, "samples", "ita_udp_server")
+    deps = [src, _SO, os.path.join(_REPO, "include", "ita_wire.h"), os.path.join(_REPO, "include", "ita_mi355x.h")]
+    if not force and os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(d) for d in deps):
+        return exe
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O2", "-std=c++17", "-Wall", "-I", os.path.join(_REPO, "include"), src, "-L", _CSRC,
+           "-lita_mi355x", "-Wl,-rpath,$ORIGIN/../csrc", "-o", exe]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return exe
 
 
 class _MhaTaps(C.Structure):
@@ -93,7 +110,11 @@ def lib():
         L.ita_tokenizer.argtypes = [vp, vp, i, vp, i, vp]
         L.ita_fusion_tail.argtypes = [vp, vp, vp, i, vp]
         L.ita_vitlstm_forward.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, vp, vp, i, C.POINTER(_FwdTaps), vp]
+        L.ita_vitlstm_forward_slots.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, i, vp, i, vp]
         L.ita_bind_dispatch.argtypes = [vp, i, i]
+        L.ita_wire_unpack_packet.argtypes = [vp, C.c_size_t, i, vp]
+        L.ita_wire_postprocess.argtypes = [vp, C.c_float, C.c_float, vp]
+        L.ita_wire_postprocess.restype = None
         L.ita_set_tail_mode.argtypes = [vp, i]
         L.ita_debug_encoder_stamps.argtypes = [vp, i, vp, vp, i, vp, vp]
         L.ita_profile_begin.argtypes = [vp, i]
@@ -291,6 +312,21 @@ class Engine:
         n = C.c_int()
         _chk(lib().ita_profile_end(self._h, ms, C.byref(n)))
         return dict(zip(self.STAGES, list(ms))), n.value
+
+    def forward_slots(self, img, desvel, quat, state_h, state_c, slot_idx):
+        """Serving form: state_h/state_c (3, num_slots, 128) persistent, updated in place for the
+        streams named by slot_idx (int32 device tensor, distinct).  Returns vel (B,3)."""
+        torch = _torch()
+        img, dt = self._image(img)
+        B = img.shape[0]
+        desvel, quat = _dev_f32(desvel).reshape(B), _dev_f32(quat, (B, 4))
+        assert state_h.is_contiguous() and state_c.is_contiguous() and state_h.dtype == torch.float32
+        slot_idx = slot_idx.to(torch.int32).contiguous()
+        vel = torch.empty((B, 3), dtype=torch.float32, device=img.device)
+        _chk(lib().ita_vitlstm_forward_slots(self._h, img.data_ptr(), dt, desvel.data_ptr(), quat.data_ptr(),
+                                             state_h.data_ptr(), state_c.data_ptr(), slot_idx.data_ptr(),
+                                             state_h.shape[1], vel.data_ptr(), B, _stream_ptr()))
+        return vel
 
     # ---- drop-in symbols (host buffers) --------------------------------------------------
     def bind_dispatch(self, layer: int = 0, dtype: int = DISPATCH_F16):

@@ -97,7 +97,7 @@ int ita_fusion_tail(ita_handle h, const float* x_dev, float* feat_dev, int batch
 /* module.main_graph with a leading batch (main.cpp:171-201; tests/export_onnx_for_FPGA.py:71-80):
  *   image (B,1,60,90) f32 or u8 wire frames, additional_data (B,1), quat_data (B,4),
  *   hidden_in_h / hidden_in_c (3,B,128)  ->  output (B,3), hidden_out_h / hidden_out_c (3,B,128).
- * hidden_out_* may alias hidden_in_*.  optional float taps (may be NULL): tokens/x1/x2 (B,128,E),
+ * hidden_out_* may alias hidden_in_* (in-place state).  optional float taps (may be NULL): tokens/x1/x2 (B,128,E),
  * feat (B,4608), dec (B,512). */
 typedef struct ita_forward_taps { float *tokens, *x1, *x2, *feat, *dec; } ita_forward_taps;
 int ita_vitlstm_forward(ita_handle h, const void* image_dev, int image_dtype, const float* additional_data_dev,
@@ -105,11 +105,20 @@ int ita_vitlstm_forward(ita_handle h, const void* image_dev, int image_dtype, co
                         float* output_dev, float* hidden_out_h_dev, float* hidden_out_c_dev, int batch,
                         const ita_forward_taps* taps, void* stream);
 
+/* Serving form of the same graph: the LSTM state of `num_slots` independent streams lives in two
+ * persistent device arrays state_h / state_c of shape (3, num_slots, 128); frame b of the batch belongs to
+ * stream slot_idx[b] (device int array, all distinct within one call) and updates that stream's state
+ * in place.  This is how the reference host carries (h, c) from frame to frame (main.cpp:143-148,217-221),
+ * generalised from one stream to many.  Needs tail mode 1. */
+int ita_vitlstm_forward_slots(ita_handle h, const void* image_dev, int image_dtype, const float* additional_data_dev,
+                              const float* quat_data_dev, float* state_h_dev, float* state_c_dev,
+                              const int* slot_idx_dev, int num_slots, float* output_dev, int batch, void* stream);
+
 /* Arithmetic of the float tail (fusion conv, decoder, LSTM) inside ita_vitlstm_forward:
  *   1 (default)  conv+decoder folded into one matrix at load time, all tail GEMMs on f16 MFMA with
  *                split-precision (hi+lo) operands: within 1e-5 of the f32 graph (task tolerance 1e-4)
  *   0            the f32 kernels in the CPU oracle's operation order: equal to the oracle bit for bit.
- * In mode 1 hidden_out_h must not alias hidden_in_h. */
+ * hidden_out_* may alias hidden_in_* in both modes. */
 int ita_set_tail_mode(ita_handle h, int mode);
 
 /* ---- per-stage timing (bench.py's roofline leg) -------------------------------------------- */
@@ -127,6 +136,12 @@ int ita_profile_end(ita_handle h, double* stage_ms, int* n_forwards);
  * of min(batch, #CUs) * 80 entries.  Not used by the product path. */
 int ita_debug_encoder_stamps(ita_handle h, int layer, const float* x_dev, float* y_dev, int batch,
                              unsigned long long* stamps_dev, void* stream);
+
+/* ---- wire format of the reference's UDP host (ita_wire.h), exported for bindings and tests ------- */
+/* frame_out: [desired_velocity, position_x, quat w, x, y, z]; returns 0, or -1 on a short packet */
+int ita_wire_unpack_packet(const uint8_t* packet, size_t nbytes, int quat_stride_bug, float* frame_out);
+/* main.cpp:381-417: clip x, normalise, scale by desired velocity, near-start x override */
+void ita_wire_postprocess(const float* raw3, float desired_velocity, float position_x, float* out3);
 
 /* ---- drop-in symbols of the reference plugin ---------------------------------------------- */
 

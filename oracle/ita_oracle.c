@@ -465,3 +465,35 @@ int ita_oracle_forward(const void* blob, size_t nbytes, const void* image, int i
   free(img); free(x); free(y); free(feat); free(cat); free(dec);
   return rc;
 }
+
+/* ------------------------------------------------------------------ UDP host (row n1) */
+/* restated from samples/inference_udp_FPGA_custom_dispatch/main.cpp:320-354 (unpack_frame, incl. its
+ * quaternion stride of sizeof(size_t) when ref_bug != 0) and :381-417 (calculate_final_velocity) */
+static float be_f32(const unsigned char* p) {
+  unsigned char b[4] = {p[3], p[2], p[1], p[0]};   /* swap_endian_4 then reinterpret on a little-endian host */
+  float f;
+  memcpy(&f, b, 4);
+  return f;
+}
+int ita_oracle_unpack_packet(const unsigned char* packet, size_t nbytes, int ref_bug, float* out6) {
+  if (nbytes < 5424) return -1;
+  size_t offset = 5400;
+  out6[0] = be_f32(packet + offset); offset += 4;
+  out6[1] = be_f32(packet + offset); offset += 4;
+  for (int i = 0; i < 4; ++i) {
+    unsigned char q[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 4; ++k) if (offset + k < nbytes) q[k] = packet[offset + k];
+    out6[2 + i] = be_f32(q);
+    offset += ref_bug ? sizeof(size_t) : 4;
+  }
+  return 0;
+}
+void ita_oracle_final_velocity(const float* raw, float desired_vel, float pos_x, float* out) {
+  float fv[3] = {raw[0], raw[1], raw[2]};
+  fv[0] = fminf(fmaxf(fv[0], -1.0f), 1.0f);
+  const float norm = sqrtf(fv[0] * fv[0] + fv[1] * fv[1] + fv[2] * fv[2]);
+  if (norm > 0.0f) { fv[0] /= norm; fv[1] /= norm; fv[2] /= norm; }
+  fv[0] *= desired_vel; fv[1] *= desired_vel; fv[2] *= desired_vel;
+  if (pos_x < 2.0f) fv[0] = fmaxf(1.0f, (pos_x / 2.0f) * desired_vel);
+  out[0] = fv[0]; out[1] = fv[1]; out[2] = fv[2];
+}

@@ -158,3 +158,17 @@ def forward(blob: bytes, image, desvel, quat, h_in=None, c_in=None, taps=False):
     if rc != 0:
         raise RuntimeError(f"ita_oracle_forward rc={rc}")
     return (vel, h_out, c_out, tp) if taps else (vel, h_out, c_out)
+
+
+def unpack_packet(packet: bytes, ref_bug: bool = False):
+    out = np.zeros(6, np.float32)
+    buf = C.create_string_buffer(packet, len(packet))
+    rc = lib().ita_oracle_unpack_packet(buf, C.c_size_t(len(packet)), int(ref_bug), _p(out))
+    return None if rc else out
+
+
+def final_velocity(raw, desired_vel, pos_x):
+    raw = _c(raw, np.float32)
+    out = np.zeros(3, np.float32)
+    lib().ita_oracle_final_velocity(_p(raw), C.c_float(desired_vel), C.c_float(pos_x), _p(out))
+    return out

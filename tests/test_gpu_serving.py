@@ -1,0 +1,94 @@
+"""Row n1 on the GPU: the slot-indexed (persistent per-stream state) forward and the UDP server
+binary end to end over the loopback interface, checked against the oracle's pipeline
+(unpack -> u8/255 -> forward -> calculate_final_velocity)."""
+import os
+import socket
+import struct
+import subprocess
+import tempfile
+import time
+
+import numpy as np
+import pytest
+
+from conftest import golden_files
+from drone_oa_iree_vit_accelerator_amd import host, params, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _blob():
+    d = params.load_fixture(golden_files("vitlstm_E64_seed0_B2.npz")[0])
+    return params.blob_from_record(d, synth.float_params(0), E=64)
+
+
+def test_forward_slots_equals_plain_forward():
+    import torch
+    blob = _blob()
+    eng = host.Engine(blob, device=0)
+    B, NS = 5, 16
+    fr = synth.frames(21, B)
+    cu = lambda a: torch.from_numpy(a).cuda()
+    img, dv, qt = cu(fr["img_u8"]), cu(fr["desvel"]), cu(fr["quat"])
+    rs = np.random.RandomState(0)
+    h0 = (0.1 * rs.standard_normal((3, NS, 128))).astype(np.float32)
+    c0 = (0.1 * rs.standard_normal((3, NS, 128))).astype(np.float32)
+    slots = np.array([7, 0, 15, 3, 9], np.int32)
+    sh, sc = cu(h0.copy()), cu(c0.copy())
+    vel = eng.forward_slots(img, dv, qt, sh, sc, cu(slots))
+    v2, (h2, c2) = eng.forward(img, dv, qt, (cu(h0[:, slots].copy()), cu(c0[:, slots].copy())))
+    assert torch.equal(vel, v2)
+    assert torch.equal(sh[:, slots.tolist()], h2) and torch.equal(sc[:, slots.tolist()], c2)
+    untouched = [i for i in range(NS) if i not in slots.tolist()]
+    np.testing.assert_array_equal(sh.cpu().numpy()[:, untouched], h0[:, untouched])
+    # in-place plain forward (hidden_out aliases hidden_in) gives the same result
+    hh, cc = cu(h0[:, slots].copy()), cu(c0[:, slots].copy())
+    v3, _ = eng.forward(img, dv, qt, (hh, cc), out=(torch.empty_like(v2), hh, cc))
+    assert torch.equal(v3, v2) and torch.equal(hh, h2) and torch.equal(cc, c2)
+    eng.close()
+
+
+def _packet(img_u8, desvel, posx, quat):
+    return img_u8.tobytes() + struct.pack(">ff", desvel, posx) + struct.pack(">4f", *[float(q) for q in quat])
+
+
+def test_udp_server_end_to_end(oracle):
+    exe = host.build_samples()
+    blob = _blob()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    nclients, steps = 3, 4
+    with tempfile.NamedTemporaryFile(suffix=".itaw") as f:
+        f.write(blob); f.flush()
+        srv = subprocess.Popen([exe, "--blob", f.name, "--port", str(port), "--max-packets", str(nclients * steps),
+                                "--max-streams", "8", "--max-batch", "8"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                               text=True)
+        try:
+            line = srv.stdout.readline()
+            assert "listening" in line, line
+            socks = [socket.socket(socket.AF_INET, socket.SOCK_DGRAM) for _ in range(nclients)]
+            for sk in socks:
+                sk.settimeout(30)
+            h = [np.zeros((3, 1, 128), np.float32) for _ in range(nclients)]
+            c = [np.zeros((3, 1, 128), np.float32) for _ in range(nclients)]
+            for t in range(steps):
+                fr = synth.frames(300 + t, nclients)
+                posx = [0.5, 1.9, 30.0]
+                for i, sk in enumerate(socks):      # all three in flight -> the server batches them
+                    sk.sendto(_packet(fr["img_u8"][i], float(fr["desvel"][i, 0]), posx[i], fr["quat"][i]),
+                              ("127.0.0.1", port))
+                for i, sk in enumerate(socks):
+                    reply, _ = sk.recvfrom(64)
+                    assert len(reply) == 12
+                    got = np.frombuffer(reply, "<f4")
+                    dv = np.float32(fr["desvel"][i, 0])
+                    vel, h[i], c[i] = oracle.forward(blob, fr["img_u8"][i:i + 1], np.array([[dv / np.float32(10.0)]], np.float32),
+                                                     fr["quat"][i:i + 1], h[i], c[i])
+                    want = oracle.final_velocity(vel[0], float(dv), posx[i])
+                    # the model output is within 4e-6 of the oracle; normalising and scaling by up to 8 m/s amplifies it
+                    np.testing.assert_allclose(got, want, atol=3e-4, rtol=0)
+            out, _ = srv.communicate(timeout=60)
+            assert srv.returncode == 0, out
+            assert f"served {nclients * steps} packets" in out
+        finally:
+            if srv.poll() is None:
+                srv.kill()
