@@ -130,3 +130,81 @@ def blob_from_record(rec: dict, float_params: dict | None, E: int, num_layers: i
 def load_fixture(path: str) -> dict:
     with np.load(path) as z:
         return {k: z[k] for k in z.files}
+
+
+# ---------------------------------------------------------------------------------------------
+# Row n4: from a reference checkpoint to the blob.
+#
+# training/qa_train.py:81-95 saves ``state_dict()`` of the CONVERTED model
+# (model_quantized_final.pth): quantized Linear layers appear as
+# ``<name>._packed_params._packed_params = (qint8 weight, float bias)`` plus ``<name>.scale``;
+# QuantStubs as ``<block>.quant.scale``; QFunctional matmuls as ``<block>.matmulN.scale``.
+# tests/export_and_validation_W_B.py:47-62,233-245 extracts the same items through module hooks;
+# here they are read straight from the state_dict, so no reference code is needed.
+
+def record_from_state_dict(sd: dict, num_layers: int = 1) -> dict:
+    """converted-model state_dict -> the fixture-style record consumed by blob_from_record"""
+    def packed(name):
+        w, b = sd[name + "._packed_params._packed_params"]
+        if int(w.q_zero_point()) != 0:
+            raise ValueError(f"{name}: weights must be symmetric (zero_point 0)")
+        return w.int_repr().numpy().astype(np.int8), float(w.q_scale()), b.detach().numpy().astype(np.float32)
+
+    def scalar(name):
+        return float(np.asarray(sd[name].detach().cpu().numpy()).reshape(-1)[0])
+
+    rec = {}
+    for i in range(num_layers):
+        a = f"attention_blocks.{i}."
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            wq, ws, b = packed(a + nm)
+            if int(sd[a + nm + ".zero_point"]) != 0:
+                raise ValueError(f"{a + nm}: output zero_point must be 0 (ita_symmetric_qconfig)")
+            rec[f"attn{i}.{nm}.w_q"], rec[f"attn{i}.{nm}.w_scale"], rec[f"attn{i}.{nm}.bias"] = wq, ws, b
+            rec[f"attn{i}.{nm}.out_scale"] = scalar(a + nm + ".scale")
+        rec[f"attn{i}.quant.scale"] = scalar(a + "quant.scale")
+        rec[f"attn{i}.matmul1.scale"] = scalar(a + "matmul1.scale")
+        rec[f"attn{i}.matmul2.scale"] = scalar(a + "matmul2.scale")
+        f = f"ffn_blocks.{i}."
+        for nm in ("fc1", "fc2"):
+            wq, ws, b = packed(f + nm)
+            rec[f"ffn{i}.{nm}.w_q"], rec[f"ffn{i}.{nm}.w_scale"], rec[f"ffn{i}.{nm}.bias"] = wq, ws, b
+            rec[f"ffn{i}.{nm}.out_scale"] = scalar(f + nm + ".scale")
+        rec[f"ffn{i}.quant.scale"] = scalar(f + "quant.scale")
+    return rec
+
+
+def fold_spectral_norm(sd: dict, name: str):
+    """torch.nn.utils.spectral_norm stores weight_orig / weight_u / weight_v; in eval mode the layer
+    uses weight_orig / sigma with sigma = u^T W v (models/ITA_single_layer_upsample_shuffle/model.py:81,84).
+    The reference's own strict=False load silently drops these keys; fold them explicitly."""
+    if name + ".weight" in sd:
+        return np.asarray(sd[name + ".weight"].detach().cpu().numpy(), np.float32)
+    w = np.asarray(sd[name + ".weight_orig"].detach().cpu().numpy(), np.float64)
+    u = np.asarray(sd[name + ".weight_u"].detach().cpu().numpy(), np.float64)
+    v = np.asarray(sd[name + ".weight_v"].detach().cpu().numpy(), np.float64)
+    sigma = float(u @ (w.reshape(w.shape[0], -1) @ v))
+    return (w / sigma).astype(np.float32)
+
+
+def float_params_from_state_dict(sd: dict, num_layers: int = 1) -> dict:
+    """non-quantised layers under the reference's state_dict names (float or converted checkpoint)"""
+    g = lambda k: np.asarray(sd[k].detach().cpu().numpy(), np.float32)
+    fp = {k: g(k) for k in ("tokenizer.conv.weight", "tokenizer.conv.bias", "tokenizer.norm.weight",
+                            "tokenizer.norm.bias", "down_sample.weight", "down_sample.bias", "decoder.bias",
+                            "nn_fc2.bias")}
+    fp["decoder.weight"] = fold_spectral_norm(sd, "decoder")
+    fp["nn_fc2.weight"] = fold_spectral_norm(sd, "nn_fc2")
+    for i in range(num_layers):
+        for nm in (f"norms1.{i}", f"norms2.{i}"):
+            fp[nm + ".weight"], fp[nm + ".bias"] = g(nm + ".weight"), g(nm + ".bias")
+    for l in range(3):
+        for nm in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+            fp[f"lstm.{nm}_l{l}"] = g(f"lstm.{nm}_l{l}")
+    return fp
+
+
+def blob_from_state_dict(sd: dict, num_layers: int = 1) -> bytes:
+    fp = float_params_from_state_dict(sd, num_layers)
+    E = fp["tokenizer.conv.weight"].shape[0]
+    return blob_from_record(record_from_state_dict(sd, num_layers), fp, E=E, num_layers=num_layers)
