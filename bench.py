@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--image-dtype", choices=["f32", "u8"], default="f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' only to "
+                    "rehearse the N>1 code path with several ranks on one GPU (set ITA_FORCE_DEVICE=0)")
     a = ap.parse_args()
 
     import torch
@@ -81,9 +83,11 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if "ITA_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["ITA_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    itadist.init("nccl", local_rank)
+    itadist.init(a.backend, local_rank)
 
     B, K, W = a.frames_per_gpu, a.steps, a.warmup
     fx = params.load_fixture(os.path.join(REPO, "tests", "golden", "vitlstm_E64_seed0_B2.npz"))
@@ -124,7 +128,7 @@ def main():
     elapsed = time.perf_counter() - t0
     stage_ms, nprof = eng.profile_end()
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if a.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -72,6 +72,14 @@ class VelocityGather:
         if self.world == 1:
             self.bufs[i].copy_(vel)
             self.handles[i] = None
+        elif dist.get_backend() == "gloo" and vel.is_cuda:
+            # rehearsal only (several ranks sharing one GPU, where RCCL refuses duplicate devices):
+            # stage through host memory, synchronously
+            import torch
+            host_out = torch.empty(self.bufs[i].shape, dtype=vel.dtype)
+            dist.all_gather_into_tensor(host_out, vel.cpu().contiguous())
+            self.bufs[i].copy_(host_out)
+            self.handles[i] = None
         else:
             self.handles[i] = dist.all_gather_into_tensor(self.bufs[i], vel.contiguous(), async_op=True)
         self.i ^= 1
