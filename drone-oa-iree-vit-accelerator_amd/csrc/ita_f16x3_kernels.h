@@ -160,9 +160,9 @@ __global__ __launch_bounds__(64 * WM * WN) void ita_gemm_f16x3_kernel(const ItaG
     stage(0, 0);
     __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
     for (int t = 0; t < nt; ++t) {
-      if (t + 1 < nt && g.dbg != 2) stage(cur ^ 1, t + 1);
-      if (g.dbg != 1) compute(cur);
-      __syncthreads();
+      if (t + 1 < nt && !(g.dbg & 2)) stage(cur ^ 1, t + 1);
+      if (!(g.dbg & 1)) compute(g.dbg & 8 ? 0 : cur);
+      if (!(g.dbg & 4)) __syncthreads();
       cur ^= 1;
     }
   } else {
@@ -220,13 +220,18 @@ struct ItaDecFinishArgs {
   int B;
   const int* slots;                     // optional: state row of frame b (persistent per-stream state), else b
 };
+template <int NS>
 __global__ void ita_dec_finish_kernel(const ItaDecFinishArgs a) {
   const int b = blockIdx.x;
   for (int j = threadIdx.x; j < a.ld; j += blockDim.x) {
     float v;
     if (j < 512) {
-      float s = a.part[(size_t)b * 512 + j];
-      for (int z = 1; z < a.nsplit; ++z) s += a.part[((size_t)z * a.B + b) * 512 + j];
+      float p[NS];
+#pragma unroll
+      for (int z = 0; z < NS; ++z) p[z] = a.part[((size_t)z * a.B + b) * 512 + j];   // all loads in flight at once
+      float s = p[0];
+#pragma unroll
+      for (int z = 1; z < NS; ++z) s += p[z];
       v = s * a.inv_wscale + a.bias[j];
       if (a.dec_tap) a.dec_tap[(size_t)b * 512 + j] = v;
     } else if (j == 512) v = a.desvel[b] / 10.0f;

@@ -53,7 +53,8 @@ struct ItaTokLds {
   static constexpr int WT = IMG + PH * PW * 4;
   static constexpr int WAVE0 = WT + 50 * E * 4;
   static constexpr int WAVE_BYTES = 32 * E * 4 > 32 * PBS * 4 ? 32 * E * 4 : 32 * PBS * 4;
-  static constexpr int TOTAL = WAVE0 + 4 * WAVE_BYTES;
+  static constexpr int LUT = WAVE0 + 4 * WAVE_BYTES;      // f32[256]: k / 255.0f (u8 wire frames)
+  static constexpr int TOTAL = LUT + 256 * 4;
 };
 
 template <int E, bool U8>
@@ -99,6 +100,10 @@ __global__ __launch_bounds__(256) void ita_tokenizer_kernel(const ItaTokArgs a) 
   }
 
   for (int i = tid; i < L::PH * PW; i += 256) img[i] = 0.0f;   // the zero border is written once
+  // u8 -> f32 exactly as the reference host does it, float(pixel) / 255.0f (main.cpp:168-169): the 256
+  // possible quotients are computed once with the IEEE division and looked up per pixel
+  float* lut = (float*)(lds + L::LUT);
+  if constexpr (U8) lut[tid] = (float)tid / 255.0f;
 
   // A frame is fetched with wide loads, all issued before the first LDS store, one frame ahead of
   // the frame being computed (a load per loop iteration would expose one memory latency each).
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(256) void ita_tokenizer_kernel(const ItaTokArgs a) 
           const int idx = 16 * p + e;
           if (idx < 5400) {
             const int y = idx / 90, x = idx - 90 * y;
-            img[(y + 3) * PW + x + 3] = (float)((unsigned)(fv[j][e >> 2] >> (8 * (e & 3))) & 0xffu) / 255.0f;
+            img[(y + 3) * PW + x + 3] = lut[((unsigned)fv[j][e >> 2] >> (8 * (e & 3))) & 0xffu];
           }
         }
       } else {

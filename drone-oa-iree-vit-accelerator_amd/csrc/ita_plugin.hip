@@ -698,7 +698,7 @@ static int forward_impl(ita_handle h, const void* image, int image_dtype, const 
     {
       ItaDecFinishArgs d{h->part, NSPLIT, h->fold_inv_scale, h->fold_bias, desvel, quat, h_in, h->c0_hi, h->c0_lo, K0F,
                          taps ? taps->dec : nullptr, B, slots};
-      hipLaunchKernelGGL(ita_dec_finish_kernel, dim3(B), dim3(256), 0, s, d);
+      hipLaunchKernelGGL(ita_dec_finish_kernel<NSPLIT>, dim3(B), dim3(256), 0, s, d);
       HIPCHK(hipGetLastError());
     }
     MARK();
