@@ -41,6 +41,25 @@ STAGE_WORK = {   # stage: (ops per frame, bound, peak in Tera-op/s, arithmetic)
 }
 
 
+# dominant-stage -> kernel whose PMC traffic (profiles/kernel_traffic.json, collected with
+# tools/profile_gpu.sh on this same command) is reported as roofline.traffic
+STAGE_KERNEL = {"encoder": "ita_encoder_kernel", "tokenizer": "ita_tokenizer_kernel<64, false>",
+                "tail_decoder": "ita_gemm_f16x3_kernel<128, 128, 2, 4, false>", "lstm_fc": "ita_lstm_layer_kernel<11>"}
+# algorithmic HBM bytes per frame of each stage as it is cut here (inputs + outputs that cross a launch)
+STAGE_BYTES = {"tokenizer": 21600 + 128 * 64 * 4, "encoder": 128 * 64 * 4 + 2 * 128 * 64 * 2,
+               "tail_decoder": 2 * 128 * 64 * 2 + 512 * 4, "lstm_fc": 2 * 3 * 128 * 4 * 2 + 12}
+
+
+def pmc_traffic(stage, frames):
+    try:
+        with open(os.path.join(REPO, "profiles", "kernel_traffic.json")) as f:
+            t = json.load(f)
+        k = t["kernels"][STAGE_KERNEL[stage]]
+        return int(k["hbm_bytes_per_launch"] * frames / 1024), t["source"]
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(blob, B_target_s=12.0):
     from drone_oa_iree_vit_accelerator_amd import synth
     from oracle import oracle
@@ -140,9 +159,12 @@ def main():
         dom = max(per, key=per.get)
         ops, bound, peak, arith = STAGE_WORK[dom]
         achieved = ops * B / (per[dom] * 1e-3) / 1e12
-        roof = {"kernel": dom, "bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 5), "traffic": None, "arithmetic": arith,
-                "ops_per_launch": ops * B, "avg_launch_ms": round(per[dom], 5), "launches_timed": nprof}
+        traffic, tsrc = pmc_traffic(dom, B)
+        roof = {"kernel": STAGE_KERNEL.get(dom, dom), "stage": dom, "bound": bound, "achieved": round(achieved, 3),
+                "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 5), "traffic": traffic,
+                "traffic_source": tsrc, "algorithmic_hbm_bytes_per_launch": STAGE_BYTES.get(dom, 0) * B,
+                "arithmetic": arith, "ops_per_launch": ops * B, "avg_launch_ms": round(per[dom], 5),
+                "launches_timed": nprof}
         stages = {}
         for k, ms in per.items():
             o, _, pk, ar = STAGE_WORK[k]
