@@ -138,14 +138,32 @@ def main():
         step(i)
     gather.finish()
     fence()
-    eng.profile_begin(min(K, 512))
+    # Untimed pass with HIP events around EVERY stage: the per-stage table and the dominant stage.
+    # (Each event costs a ~5 us bubble in the stream, so this pass is ~20 % slower than the timed one.)
+    NP = 20
+    eng.profile_begin(NP)
+    for i in range(NP):
+        step(W + i)
+    gather.finish()
+    fence()
+    stage_all, n_all = eng.profile_end()
+    per = {k: v / max(n_all, 1) for k, v in stage_all.items()}
+    per["tail_decoder"] = per.pop("tail") + per.pop("decoder")
+    per["encoder"] = per.pop("mha") + per.pop("ffn")
+    dom = max(per, key=per.get)
+    dom_plugin_stage = {"encoder": "mha", "tail_decoder": "tail", "lstm_fc": "lstm_fc", "tokenizer": "tokenizer"}[dom]
+    # Timed region: exactly K steps; HIP events only around the dominant kernel, on every 8th step
+    # (its average launch duration for the roofline is measured here, live, on the compute stream).
+    if not os.environ.get("ITA_BENCH_NOPROF"):
+        eng.profile_begin(min(K, 512), every_n=8, only_stage=dom_plugin_stage)
     t0 = time.perf_counter()
     for i in range(K):
-        step(W + i)
+        step(W + NP + i)
     gather.finish()
     fence()
     elapsed = time.perf_counter() - t0
     stage_ms, nprof = eng.profile_end()
+    dom_ms = stage_ms[dom_plugin_stage] / max(nprof, 1)
     if world > 1:
         t = torch.tensor([elapsed], device=dev if a.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -153,18 +171,16 @@ def main():
 
     out = None
     if rank == 0:
-        per = {k: v / max(nprof, 1) for k, v in stage_ms.items()}
-        per["tail_decoder"] = per.pop("tail") + per.pop("decoder")
-        per["encoder"] = per.pop("mha") + per.pop("ffn")
-        dom = max(per, key=per.get)
         ops, bound, peak, arith = STAGE_WORK[dom]
-        achieved = ops * B / (per[dom] * 1e-3) / 1e12
+        if nprof == 0:
+            dom_ms = per[dom]
+        achieved = ops * B / (max(dom_ms, 1e-9) * 1e-3) / 1e12
         traffic, tsrc = pmc_traffic(dom, B)
         roof = {"kernel": STAGE_KERNEL.get(dom, dom), "stage": dom, "bound": bound, "achieved": round(achieved, 3),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 5), "traffic": traffic,
                 "traffic_source": tsrc, "algorithmic_hbm_bytes_per_launch": STAGE_BYTES.get(dom, 0) * B,
-                "arithmetic": arith, "ops_per_launch": ops * B, "avg_launch_ms": round(per[dom], 5),
-                "launches_timed": nprof}
+                "arithmetic": arith, "ops_per_launch": ops * B, "avg_launch_ms": round(dom_ms, 5),
+                "launches_timed": nprof, "timing": "HIP events around this kernel on every 8th step of the timed region"}
         stages = {}
         for k, ms in per.items():
             o, _, pk, ar = STAGE_WORK[k]
@@ -181,6 +197,8 @@ def main():
                        "frames_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "image_dtype": a.image_dtype, "weights": "seed-0 synthetic QAT (tests/golden)"},
             "roofline": roof, "stages": stages,
+            "stages_note": "per-stage times from an untimed 20-step pass with events around every stage (each event "
+                           "costs a ~5 us stream bubble, so they sum to more than ms_per_step)",
         }
         if not a.no_latency:      # p50 single-frame latency, host enqueue -> result ready
             e1 = host.Engine(blob, device=local_rank, reserve=1)

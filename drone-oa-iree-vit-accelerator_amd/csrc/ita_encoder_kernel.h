@@ -34,6 +34,12 @@ struct ItaEncArgs {
   // diagnostic only (null in production): wave 0 of each workgroup stores s_memtime at the 10 phase
   // boundaries of its first 8 frames: stamps[(block * 8 + frame) * 10 + phase]
   unsigned long long* stamps;
+  // optional side copy for the LSTM that follows: layer-0 hidden state of frame b (row slots[b] or b of
+  // h0_src) -> h0_dst[b].  Layer 0 reads whole rows of h while other workgroups overwrite parts of the
+  // same row when the state is updated in place; the staged copy removes that race.
+  const float* h0_src;
+  float* h0_dst;
+  const int* slots;
 };
 
 struct ItaEncLds {
@@ -177,6 +183,10 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
       *(i32x4*)(lds + L::XQ + cm_off(token, qtr * EC, 128)) = (i32x4){(int)p4[0], (int)p4[1], (int)p4[2], (int)p4[3]};
     }
     if (tid < P) colsum[tid] = 0;
+    if (a.h0_dst && tid < 32) {
+      const size_t row = a.slots ? (size_t)a.slots[b] : (size_t)b;
+      *(f32x4*)(a.h0_dst + (size_t)b * 128 + 4 * tid) = *(const f32x4*)(a.h0_src + row * 128 + 4 * tid);
+    }
     lds_barrier();
     ITA_STAMP(1);
 

@@ -16,9 +16,9 @@
 // exact f32 tail + decoder kernels) and the whole tail becomes  dec = x2 . Wfold^T + bias'.
 //
 //   ita_gemm_f16x3_kernel<BM,BN>   C_partial[z][m][n] = sum_{k in slice z} A[m][k] W[n][k]
-//   ita_dec_finish_kernel          sums split-K partials (fixed order), adds bias', emits the
-//                                  LSTM layer-0 input [dec | desvel/10 | quat | h_in0] as planes
-//   ita_lstm_cell_kernel           gate non-linearities, state update, next layer's planes, fc
+//   ita_lstm0_kernel               LSTM layer 0: sums the split-K partials (the decoder is folded into
+//                                  its input projection), adds the [h | desvel | quat] remainder, cell update
+//   ita_lstm_layer_kernel<NK>      LSTM layers 1, 2: [x | h] GEMM fused with the cell update
 #pragma once
 #include "ita_device.h"
 
@@ -207,42 +207,116 @@ __global__ __launch_bounds__(64 * WM * WN) void ita_gemm_f16x3_kernel(const ItaG
     }
 }
 
-// ------------------------------------------------------------------ decoder finish + LSTM-0 input
-struct ItaDecFinishArgs {
-  const float* part;      // [nsplit][B][512] raw accumulators of x2 . (Wfold * wscale)^T
-  int nsplit;
-  float inv_wscale;
-  const float* bias;      // [512] folded bias  dec(tail(0))
-  const float *desvel, *quat, *h_in0;   // (B), (B,4), (B,128) layer-0 hidden state
-  _Float16 *cat_hi, *cat_lo;            // [B][ld] planes: dec | desvel/10 | quat | h_in0 | 0
-  int ld;                               // 704
-  float* dec_tap;                       // optional (B,512) f32
+// ------------------------------------------------------------------ LSTM layer 0
+// The decoder Linear feeds nothing but LSTM layer 0 (QAT/model.py:124-128), so its weights are folded
+// one step further at load time:  G0 = W_ih0[:, :512] . Wfold  (512 x 8192).  The big GEMM then
+// yields layer 0's gate pre-activations directly (as split-K partials, columns in the permuted
+// gate order below) and this kernel only adds the small remainder
+//     [h_in0 | desvel/10 | quat] . [W_hh0 | W_ih0[:, 512:517]]^T        (K = 133, padded to 144)
+// sums the partials in a fixed order, and performs the cell update.
+// One wave per workgroup = 32 frames x 8 units; grid (16, ceil(B/32)); every load is issued before the
+// first MFMA.
+struct ItaLstm0Args {
+  const float* part; int nsplit; float inv_fold_scale;   // [nsplit][B][512] raw accumulators of x2 . (G0 * scale)^T
+  const _Float16 *w_hi, *w_lo; float inv_wscale;         // [512][144] permuted rows, pre-scaled: [W_hh0 | w_dv | w_quat | 0]
+  const float* bias;                                     // [512] gate-major: W_ih0[:, :512].bias' + b_ih0 + b_hh0
+  const float *desvel, *quat;                            // (B), (B,4)
+  const float* h_in;                                     // (B,128) layer-0 hidden state STAGED by frame index
+  const float* c_in;                                     // layer-0 cell state rows (slot- or frame-indexed)
+  float *h_out, *c_out;
+  _Float16 *nx_hi, *nx_lo; const float* nx_h_in;         // layer 1 planes [B][256] = [h_out | h_in1]
   int B;
-  const int* slots;                     // optional: state row of frame b (persistent per-stream state), else b
+  const int* slots;
 };
 template <int NS>
-__global__ void ita_dec_finish_kernel(const ItaDecFinishArgs a) {
-  const int b = blockIdx.x;
-  for (int j = threadIdx.x; j < a.ld; j += blockDim.x) {
-    float v;
-    if (j < 512) {
-      float p[NS];
+__global__ __launch_bounds__(64) void ita_lstm0_kernel(const ItaLstm0Args a) {
+  const int lane = threadIdx.x;
+  const int ut = blockIdx.x, r = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y * 32 + r;
+  const int bc = min(b, a.B - 1);
+  const size_t sb = a.slots ? (size_t)a.slots[bc] : (size_t)bc;
+  // split-K partials of this lane's 16 gate values: issue all loads first
+  const int u0 = ut * 8 + 4 * h;
+  f32x4 pz[NS][4];
 #pragma unroll
-      for (int z = 0; z < NS; ++z) p[z] = a.part[((size_t)z * a.B + b) * 512 + j];   // all loads in flight at once
-      float s = p[0];
+  for (int z = 0; z < NS; ++z)
 #pragma unroll
-      for (int z = 1; z < NS; ++z) s += p[z];
-      v = s * a.inv_wscale + a.bias[j];
-      if (a.dec_tap) a.dec_tap[(size_t)b * 512 + j] = v;
-    } else if (j == 512) v = a.desvel[b] / 10.0f;
-    else if (j < 517) v = a.quat[(size_t)b * 4 + j - 513];
-    else if (j < 645) v = a.h_in0[(size_t)(a.slots ? a.slots[b] : b) * 128 + j - 517];
-    else v = 0.0f;
-    _Float16 hi, lo;
-    split_f16(v, hi, lo);
-    a.cat_hi[(size_t)b * a.ld + j] = hi;
-    a.cat_lo[(size_t)b * a.ld + j] = lo;
+    for (int gt = 0; gt < 4; ++gt)
+      pz[z][gt] = *(const f32x4*)(a.part + ((size_t)z * a.B + bc) * 512 + ut * 32 + gt * 8 + 4 * h);
+  // small GEMM: A operand = weights (rows = permuted gates), B operand = this frame's [h | dv | quat]
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+  const _Float16* wrow_hi = a.w_hi + (size_t)(ut * 32 + r) * 144 + 8 * h;
+  const _Float16* wrow_lo = a.w_lo + (size_t)(ut * 32 + r) * 144 + 8 * h;
+  const float* hrow = a.h_in + (size_t)bc * 128 + 8 * h;
+  f32x4 xa[9][2];
+  f16x8 wh[9], wl[9];
+#pragma unroll
+  for (int s = 0; s < 9; ++s) {
+    if (s < 8) {
+      xa[s][0] = *(const f32x4*)(hrow + 16 * s);
+      xa[s][1] = *(const f32x4*)(hrow + 16 * s + 4);
+    } else {
+      xa[s][0] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+      xa[s][1] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+      if (h == 0) {
+        const f32x4 q = *(const f32x4*)(a.quat + (size_t)bc * 4);
+        xa[s][0] = (f32x4){a.desvel[bc] / 10.0f, q.x, q.y, q.z};
+        xa[s][1].x = q.w;
+      }
+    }
+    wh[s] = *(const f16x8*)(wrow_hi + 16 * s);
+    wl[s] = *(const f16x8*)(wrow_lo + 16 * s);
   }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < 9; ++s) {
+    f16x8 xh, xl;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = xa[s][j >> 2][j & 3];
+      const _Float16 hi = (_Float16)x;
+      xh[j] = hi;
+      xl[j] = (_Float16)(x - (float)hi);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[s], xh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], xl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], xh, acc, 0, 0, 0);
+  }
+  if (b >= a.B) return;
+  // acc[4*gate + q] <-> gate (i,f,g,o), unit u0 + q, frame b
+  const f32x4 ci = *(const f32x4*)(a.c_in + sb * 128 + u0);
+  f32x4 hn, cn;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float g[4];
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt) {
+      float ps = pz[0][gt][q];
+#pragma unroll
+      for (int z = 1; z < NS; ++z) ps += pz[z][gt][q];
+      g[gt] = (ps * a.inv_fold_scale + acc[4 * gt + q] * a.inv_wscale) + a.bias[gt * 128 + u0 + q];
+    }
+    const float ig = ita_sigmoid(g[0]), fg = ita_sigmoid(g[1]), cg = ita_tanh(g[2]), og = ita_sigmoid(g[3]);
+    const float c = fmaf(fg, ci[q], ig * cg);
+    cn[q] = c;
+    hn[q] = og * ita_tanh(c);
+  }
+  *(f32x4*)(a.c_out + sb * 128 + u0) = cn;
+  *(f32x4*)(a.h_out + sb * 128 + u0) = hn;
+  const f32x4 nh = *(const f32x4*)(a.nx_h_in + sb * 128 + u0);
+  f16x4 h_hi, h_lo, n_hi, n_lo;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    _Float16 x, y;
+    split_f16(hn[q], x, y); h_hi[q] = x; h_lo[q] = y;
+    split_f16(nh[q], x, y); n_hi[q] = x; n_lo[q] = y;
+  }
+  *(f16x4*)(a.nx_hi + (size_t)b * 256 + u0) = h_hi;
+  *(f16x4*)(a.nx_lo + (size_t)b * 256 + u0) = h_lo;
+  *(f16x4*)(a.nx_hi + (size_t)b * 256 + 128 + u0) = n_hi;
+  *(f16x4*)(a.nx_lo + (size_t)b * 256 + 128 + u0) = n_lo;
 }
 
 // ------------------------------------------------------------------ one LSTM layer per launch

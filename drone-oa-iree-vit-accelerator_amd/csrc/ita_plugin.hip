@@ -38,7 +38,7 @@ int fail(int code, const std::string& msg) {
   } while (0)
 
 constexpr int K0P = 672;    // exact-f32 path: LSTM layer-0 concat width 517 + 128 = 645, padded to a multiple of 32
-constexpr int K0F = 704;    // f16x3 path: padded to a multiple of 64
+constexpr int K0S = 144;    // f16x3 path, LSTM layer 0 remainder: [h_in0 (128) | desvel | quat (4) | 0 pad]
 constexpr int KFOLD = 8192; // 128 tokens x 64 channels feeding the folded tail+decoder matrix
 constexpr int LDFOLD = KFOLD + 64;   // row stride of the x2 / Wfold planes: a power-of-two stride (16 KB) would put
                                      // every row of a K tile on the same L2 channel
@@ -72,13 +72,13 @@ struct ita_context {
   // split-precision (f16 hi/lo) tail: folded tail+decoder matrix and LSTM weights, pre-scaled
   int tail_mode = 1;                       // 1: folded f16x3 GEMMs (default), 0: exact f32 kernels
   bool folded = false;
-  _Float16 *fold_hi = nullptr, *fold_lo = nullptr;   // [512][8192]
-  float* fold_bias = nullptr;                        // [512] = dec(tail(0))
+  _Float16 *fold_hi = nullptr, *fold_lo = nullptr;   // [512][LDFOLD]: G0 = W_ih0[:, :512] . Wfold, rows in permuted gate order
+  float* fold_bias = nullptr;                        // [512] gate-major: W_ih0[:, :512] . dec(tail(0)) + b_ih0 + b_hh0
   float fold_inv_scale = 1.0f;
-  _Float16 *lw_hi[3] = {nullptr, nullptr, nullptr}, *lw_lo[3] = {nullptr, nullptr, nullptr};   // [512][K0F | 256]
+  _Float16 *lw_hi[3] = {nullptr, nullptr, nullptr}, *lw_lo[3] = {nullptr, nullptr, nullptr};   // [512][K0S | 256 | 256]
   float lw_inv_scale[3] = {1.0f, 1.0f, 1.0f};
   // workspace of the f16x3 path
-  _Float16 *x2_hi = nullptr, *x2_lo = nullptr, *c0_hi = nullptr, *c0_lo = nullptr, *c1_hi = nullptr, *c1_lo = nullptr,
+  _Float16 *x2_hi = nullptr, *x2_lo = nullptr, *c1_hi = nullptr, *c1_lo = nullptr,
            *c2_hi = nullptr, *c2_lo = nullptr;
   float* part = nullptr;
   // workspace
@@ -88,6 +88,7 @@ struct ita_context {
   // per-stage profiling (ita_profile_begin / _end)
   bool prof = false;
   int prof_max = 0, prof_n = 0;
+  int prof_every = 1, prof_stage = -1, prof_calls = 0;   // sample every n-th forward; -1 = all stages, else one stage
   std::vector<hipEvent_t> prof_ev;   // per recorded forward: 1 + 1 + 2*L + 3 events
   // staging for the host-buffer drop-in symbols
   float *dsp_in = nullptr, *dsp_out = nullptr;
@@ -145,7 +146,7 @@ void free_workspace(ita_context* c) {
     if (*b) (void)hipFree(*b);
     *b = nullptr;
   }
-  _Float16** hb[] = {&c->x2_hi, &c->x2_lo, &c->c0_hi, &c->c0_lo, &c->c1_hi, &c->c1_lo, &c->c2_hi, &c->c2_lo};
+  _Float16** hb[] = {&c->x2_hi, &c->x2_lo, &c->c1_hi, &c->c1_lo, &c->c2_hi, &c->c2_lo};
   for (_Float16** b : hb) {
     if (*b) (void)hipFree(*b);
     *b = nullptr;
@@ -168,8 +169,6 @@ int ensure_workspace(ita_context* c, int B) {
   HIPCHK(hipMalloc(&c->gates, sizeof(float) * (size_t)B * 512));
   HIPCHK(hipMalloc(&c->x2_hi, 2 * (size_t)B * LDFOLD));
   HIPCHK(hipMalloc(&c->x2_lo, 2 * (size_t)B * LDFOLD));
-  HIPCHK(hipMalloc(&c->c0_hi, 2 * (size_t)B * K0F));
-  HIPCHK(hipMalloc(&c->c0_lo, 2 * (size_t)B * K0F));
   HIPCHK(hipMalloc(&c->c1_hi, 2 * (size_t)B * 256));
   HIPCHK(hipMalloc(&c->c1_lo, 2 * (size_t)B * 256));
   HIPCHK(hipMalloc(&c->c2_hi, 2 * (size_t)B * 256));
@@ -246,7 +245,8 @@ int launch_ffn(ita_context* c, int layer, const float* x, float* y, int B, bool 
 
 // whole encoder layer in one launch (E = 64)
 int launch_encoder(ita_context* c, int layer, const float* x, float* y, _Float16* y_hi, _Float16* y_lo, float* x1_tap,
-                   int B, hipStream_t s, unsigned long long* stamps = nullptr) {
+                   int B, hipStream_t s, unsigned long long* stamps = nullptr, const float* h0_src = nullptr,
+                   float* h0_dst = nullptr, const int* slots = nullptr) {
   const Layer& L = c->layers[layer];
   if (!L.n1w || !L.n2w) return fail(ITA_ERR_BAD_BLOB, "LayerNorm parameters missing from the blob");
   ItaEncArgs a{};
@@ -260,6 +260,7 @@ int launch_encoder(ita_context* c, int layer, const float* x, float* y, _Float16
   a.B = B;
   a.ld_planes = LDFOLD;
   a.stamps = stamps;
+  a.h0_src = h0_src; a.h0_dst = h0_dst; a.slots = slots;
   const int grid = B < c->num_cus ? B : c->num_cus;
   hipLaunchKernelGGL(ita_encoder_kernel, dim3(grid), dim3(512), ItaEncLds::TOTAL, s, a);
   HIPCHK(hipGetLastError());
@@ -377,16 +378,34 @@ int build_fold(ita_context* c) {
   if (!rc) {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(hb.data(), imp, 512 * sizeof(float), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(hmt.data(), mt, hmt.size() * sizeof(float), hipMemcpyDeviceToHost));
+    // one fold further: the decoder output feeds only LSTM layer 0, so
+    //   G0^T[k][j] = sum_n Wfold^T[k][n] * W_ih0[j][n]        (wcat[0] holds W_ih0 in its first 517 columns)
+    // computed with the exact f32 GEMM; the buffer that held the impulses is reused for the result
+    rc = launch_gemm(mt, 512, c->wcat[0], K0P, nullptr, imp, 512, KFOLD, 512, 512, nullptr);
+  }
+  if (!rc) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(hmt.data(), imp, hmt.size() * sizeof(float), hipMemcpyDeviceToHost));
   }
   (void)hipFree(imp); (void)hipFree(feat); (void)hipFree(mt); (void)hipFree(zero);
   if (rc) return rc;
+  // rows of the GEMM weight in the permuted gate order r' = ut*32 + gate*8 + u (ita_lstm0_kernel)
   std::vector<float> wf((size_t)512 * LDFOLD, 0.0f);
-  for (int k = 0; k < KFOLD; ++k)
-    for (int j = 0; j < 512; ++j) wf[(size_t)j * LDFOLD + k] = hmt[(size_t)k * 512 + j];
+  for (int rp = 0; rp < 512; ++rp) {
+    const int j = ((rp >> 3) & 3) * 128 + (rp >> 5) * 8 + (rp & 7);
+    for (int k = 0; k < KFOLD; ++k) wf[(size_t)rp * LDFOLD + k] = hmt[(size_t)k * 512 + j];
+  }
   if ((rc = split_upload(wf, &c->fold_hi, &c->fold_lo, &c->fold_inv_scale))) return rc;
+  // bias'' = W_ih0[:, :512] . bias' + b_ih0 + b_hh0   (gate-major order)
+  const float *wih0 = hptr<float>(c, "lstm.w_ih0"), *bih0 = hptr<float>(c, "lstm.b_ih0"), *bhh0 = hptr<float>(c, "lstm.b_hh0");
+  std::vector<float> b2(512);
+  for (int j = 0; j < 512; ++j) {
+    double acc = (double)bih0[j] + (double)bhh0[j];
+    for (int n = 0; n < 512; ++n) acc += (double)wih0[(size_t)j * 517 + n] * (double)hb[n];
+    b2[j] = (float)acc;
+  }
   HIPCHK(hipMalloc(&c->fold_bias, 512 * sizeof(float)));
-  HIPCHK(hipMemcpy(c->fold_bias, hb.data(), 512 * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->fold_bias, b2.data(), 512 * sizeof(float), hipMemcpyHostToDevice));
   c->folded = true;
   return ITA_OK;
 }
@@ -550,13 +569,19 @@ int ita_load_weights(ita_handle h, const void* blob, size_t nbytes) {
       HIPCHK(hipMemcpy(h->wcat[l], wc.data(), wc.size() * sizeof(float), hipMemcpyHostToDevice));
       HIPCHK(hipMalloc(&h->bsum[l], 512 * sizeof(float)));
       HIPCHK(hipMemcpy(h->bsum[l], bs.data(), 512 * sizeof(float), hipMemcpyHostToDevice));
-      // split-precision planes of the same concatenated matrix (layer 0 padded to K0F)
-      const int kf = l == 0 ? K0F : 256;
-      // rows permuted to r' = ut*32 + gate*8 + u so that one MFMA tile holds i,f,g,o of 8 units
+      // split-precision planes, rows permuted to r' = ut*32 + gate*8 + u so that one MFMA tile holds
+      // i,f,g,o of 8 units.  Layers 1, 2: the concatenated [W_ih | W_hh].  Layer 0: only what the folded
+      // GEMM does not cover, [W_hh0 (128) | W_ih0[:,512] (desvel) | W_ih0[:,513:517] (quat) | 0] (K0S wide).
+      const int kf = l == 0 ? K0S : 256;
       std::vector<float> wf((size_t)512 * kf, 0.0f);
       for (int rp = 0; rp < 512; ++rp) {
         const int j = ((rp >> 3) & 3) * 128 + (rp >> 5) * 8 + (rp & 7);
-        memcpy(&wf[(size_t)rp * kf], &wc[(size_t)j * kp], sizeof(float) * (in + 128));
+        if (l == 0) {
+          memcpy(&wf[(size_t)rp * kf], whh + (size_t)j * 128, sizeof(float) * 128);
+          memcpy(&wf[(size_t)rp * kf + 128], wih + (size_t)j * 517 + 512, sizeof(float) * 5);
+        } else {
+          memcpy(&wf[(size_t)rp * kf], &wc[(size_t)j * kp], sizeof(float) * 256);
+        }
       }
       int rc2 = split_upload(wf, &h->lw_hi[l], &h->lw_lo[l], &h->lw_inv_scale[l]);
       if (rc2) { free_weights(h); return rc2; }
@@ -660,9 +685,18 @@ static int forward_impl(ita_handle h, const void* image, int image_dtype, const 
   if (slots && !fast) return fail(ITA_ERR_UNSUPPORTED, "slot-indexed state needs tail mode 1");
   const size_t lstride = (size_t)(slots ? state_rows : batch) * 128;   // layer stride of the (3, rows, 128) state
   const int ev_per_fwd = 5 + 2 * h->hdr.num_layers;
-  hipEvent_t* ev = (h->prof && h->prof_n < h->prof_max) ? &h->prof_ev[(size_t)h->prof_n * ev_per_fwd] : nullptr;
-  int evi = 0;
-#define MARK() do { if (ev) HIPCHK(hipEventRecord(ev[evi++], s)); } while (0)
+  hipEvent_t* ev = nullptr;
+  if (h->prof && h->prof_n < h->prof_max && (h->prof_calls++ % h->prof_every) == 0)
+    ev = &h->prof_ev[(size_t)h->prof_n * ev_per_fwd];
+  // an event in the stream costs a pipeline bubble of ~5 us (the next kernel cannot be launched
+  // under the tail of the previous one), so in single-stage mode only that stage's two marks are recorded
+  int evi = 0, m_lo = 0, m_hi = ev_per_fwd - 1;
+  if (h->prof_stage >= 0) {
+    const int L2 = 2 * h->hdr.num_layers;
+    const int lo[ITA_NUM_STAGES] = {0, 1, 1, 1 + L2, 2 + L2, 3 + L2}, hi[ITA_NUM_STAGES] = {1, 1 + L2, 1 + L2, 2 + L2, 3 + L2, 4 + L2};
+    m_lo = lo[h->prof_stage]; m_hi = hi[h->prof_stage];
+  }
+#define MARK() do { if (ev && (h->prof_stage < 0 || evi == m_lo || evi == m_hi)) HIPCHK(hipEventRecord(ev[evi], s)); ++evi; } while (0)
   MARK();
   if ((rc = launch_tokenizer(h, image, image_dtype, h->bufA, B, s))) return rc;
   MARK();
@@ -673,7 +707,8 @@ static int forward_impl(ita_handle h, const void* image, int image_dtype, const 
     float* yout = (planes && !(taps && taps->x2)) ? nullptr : h->bufA;
     if (h->hdr.E == 64) {     // fused encoder layer, in place on bufA
       if ((rc = launch_encoder(h, l, h->bufA, yout, planes ? h->x2_hi : nullptr, planes ? h->x2_lo : nullptr,
-                               (taps && last) ? taps->x1 : nullptr, B, s))) return rc;
+                               (taps && last) ? taps->x1 : nullptr, B, s, nullptr, planes ? h_in : nullptr,
+                               planes ? h->gates : nullptr, slots))) return rc;
       MARK();
       MARK();
     } else {
@@ -695,23 +730,22 @@ static int forward_impl(ita_handle h, const void* image, int image_dtype, const 
     } else if ((rc = launch_gemm_split<128, 128, 2, 4>(h->x2_hi, h->x2_lo, LDFOLD, h->fold_hi, h->fold_lo, LDFOLD, h->part, B,
                                                        512, KFOLD, NSPLIT, s))) return rc;
     MARK();
+    MARK();
+    _Float16* chi[3] = {nullptr, h->c1_hi, h->c2_hi};
+    _Float16* clo[3] = {nullptr, h->c1_lo, h->c2_lo};
     {
-      ItaDecFinishArgs d{h->part, NSPLIT, h->fold_inv_scale, h->fold_bias, desvel, quat, h_in, h->c0_hi, h->c0_lo, K0F,
-                         taps ? taps->dec : nullptr, B, slots};
-      hipLaunchKernelGGL(ita_dec_finish_kernel<NSPLIT>, dim3(B), dim3(256), 0, s, d);
+      ItaLstm0Args p{h->part, NSPLIT, h->fold_inv_scale, h->lw_hi[0], h->lw_lo[0], h->lw_inv_scale[0], h->fold_bias,
+                     desvel, quat, h->gates /* staged h_in0, by frame */, c_in, h_out, c_out, chi[1], clo[1],
+                     h_in + lstride, B, slots};
+      hipLaunchKernelGGL(ita_lstm0_kernel<NSPLIT>, dim3(16, (B + 31) / 32), dim3(64), 0, s, p);
       HIPCHK(hipGetLastError());
     }
-    MARK();
-    _Float16* chi[3] = {h->c0_hi, h->c1_hi, h->c2_hi};
-    _Float16* clo[3] = {h->c0_lo, h->c1_lo, h->c2_lo};
-    const int kf[3] = {K0F, 256, 256};
-    for (int l = 0; l < 3; ++l) {
-      ItaLstmLayerArgs p{chi[l], clo[l], kf[l], h->lw_hi[l], h->lw_lo[l], kf[l], h->lw_inv_scale[l], h->bsum[l],
+    for (int l = 1; l < 3; ++l) {
+      ItaLstmLayerArgs p{chi[l], clo[l], 256, h->lw_hi[l], h->lw_lo[l], 256, h->lw_inv_scale[l], h->bsum[l],
                          c_in + l * lstride, h_out + l * lstride, c_out + l * lstride,
                          l < 2 ? chi[l + 1] : nullptr, l < 2 ? clo[l + 1] : nullptr,
-                         l < 2 ? h_in + (l + 1) * lstride : nullptr, B, kf[l], slots};
-      if (l == 0) hipLaunchKernelGGL(ita_lstm_layer_kernel<K0F / 64>, dim3(16, (B + 31) / 32), dim3(256), 0, s, p);
-      else hipLaunchKernelGGL(ita_lstm_layer_kernel<4>, dim3(16, (B + 31) / 32), dim3(256), 0, s, p);
+                         l < 2 ? h_in + (l + 1) * lstride : nullptr, B, 256, slots};
+      hipLaunchKernelGGL(ita_lstm_layer_kernel<4>, dim3(16, (B + 31) / 32), dim3(256), 0, s, p);
       HIPCHK(hipGetLastError());
     }
     hipLaunchKernelGGL(ita_fc_kernel, dim3((B * 3 + 63) / 64), dim3(64), 0, s, h_out + 2 * lstride, h->fc_w,
@@ -767,10 +801,16 @@ int ita_vitlstm_forward_slots(ita_handle h, const void* image, int image_dtype, 
                       slot_idx, num_slots);
 }
 
-int ita_profile_begin(ita_handle h, int max_forwards) {
+int ita_profile_begin(ita_handle h, int max_forwards) { return ita_profile_begin_sampled(h, max_forwards, 1, -1); }
+
+int ita_profile_begin_sampled(ita_handle h, int max_forwards, int every_n, int only_stage) {
   int rc = check(h, 1);
   if (rc) return rc;
   if (max_forwards <= 0 || max_forwards > 4096) return fail(ITA_ERR_INVALID_ARG, "max_forwards out of range");
+  if (every_n < 1 || only_stage < -1 || only_stage >= ITA_NUM_STAGES) return fail(ITA_ERR_INVALID_ARG, "bad sampling arguments");
+  h->prof_every = every_n;
+  h->prof_stage = only_stage;
+  h->prof_calls = 0;
   const size_t need = (size_t)max_forwards * (5 + 2 * h->hdr.num_layers);
   while (h->prof_ev.size() < need) {
     hipEvent_t e;
@@ -791,7 +831,7 @@ int ita_profile_end(ita_handle h, double* stage_ms, int* n_forwards) {
   for (int i = 0; i < ITA_NUM_STAGES; ++i) stage_ms[i] = 0.0;
   for (int f = 0; f < h->prof_n; ++f) {
     hipEvent_t* ev = &h->prof_ev[(size_t)f * per];
-    HIPCHK(hipEventSynchronize(ev[per - 1]));
+    HIPCHK(hipEventSynchronize(ev[h->prof_stage >= 0 ? (h->prof_stage == 0 ? 1 : (h->prof_stage <= 2 ? 1 + 2 * L : h->prof_stage - 1 + 2 * L)) : per - 1]));
     auto dt = [&](int a, int b, double* acc) -> int {
       float ms = 0.0f;
       HIPCHK(hipEventElapsedTime(&ms, ev[a], ev[b]));
@@ -799,6 +839,11 @@ int ita_profile_end(ita_handle h, double* stage_ms, int* n_forwards) {
       return ITA_OK;
     };
     int rc;
+    if (h->prof_stage >= 0) {     // single-stage mode: only that stage's two marks exist
+      const int lo[ITA_NUM_STAGES] = {0, 1, 1, 1 + 2 * L, 2 + 2 * L, 3 + 2 * L}, hi[ITA_NUM_STAGES] = {1, 1 + 2 * L, 1 + 2 * L, 2 + 2 * L, 3 + 2 * L, 4 + 2 * L};
+      if ((rc = dt(lo[h->prof_stage], hi[h->prof_stage], &stage_ms[h->prof_stage]))) return rc;
+      continue;
+    }
     if ((rc = dt(0, 1, &stage_ms[0]))) return rc;
     for (int l = 0; l < L; ++l) {
       if ((rc = dt(1 + 2 * l, 2 + 2 * l, &stage_ms[1]))) return rc;

@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = (
     "ita_abi_version", "ita_create", "ita_destroy", "ita_load_weights", "ita_reserve", "ita_get_dims",
     "ita_last_error", "ita_error_string", "ita_mha_int8", "ita_mha_int8_taps", "ita_ffn_int8", "ita_ffn_int8_taps",
     "ita_encoder_layer", "ita_tokenizer", "ita_fusion_tail", "ita_vitlstm_forward", "ita_bind_dispatch",
-    "ita_profile_begin", "ita_profile_end", "ita_set_tail_mode", "ita_debug_encoder_stamps",
+    "ita_profile_begin", "ita_profile_begin_sampled", "ita_profile_end", "ita_set_tail_mode", "ita_debug_encoder_stamps",
     "ita_wire_unpack_packet", "ita_wire_postprocess", "ita_vitlstm_forward_slots",
     "ITASelfAttention_workgroup", "ITASelfAttention_workgroup_expanded", "ITAFeedForward_workgroup",
 )
@@ -118,6 +118,7 @@ def lib():
         L.ita_set_tail_mode.argtypes = [vp, i]
         L.ita_debug_encoder_stamps.argtypes = [vp, i, vp, vp, i, vp, vp]
         L.ita_profile_begin.argtypes = [vp, i]
+        L.ita_profile_begin_sampled.argtypes = [vp, i, i, i]
         L.ita_profile_end.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i)]
         L.ITASelfAttention_workgroup.argtypes = [vp, vp]
         L.ITASelfAttention_workgroup.restype = None
@@ -303,8 +304,10 @@ class Engine:
     # ---- per-stage device timing ---------------------------------------------------------
     STAGES = ("tokenizer", "mha", "ffn", "tail", "decoder", "lstm_fc")
 
-    def profile_begin(self, max_forwards: int):
-        _chk(lib().ita_profile_begin(self._h, max_forwards))
+    def profile_begin(self, max_forwards: int, every_n: int = 1, only_stage: Optional[str] = None):
+        """only_stage: one of STAGES -> record only that stage's two events, on every every_n-th forward"""
+        st = -1 if only_stage is None else self.STAGES.index(only_stage)
+        _chk(lib().ita_profile_begin_sampled(self._h, max_forwards, every_n, st))
 
     def profile_end(self):
         """-> ({stage: summed ms}, forwards covered)"""

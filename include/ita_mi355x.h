@@ -115,8 +115,10 @@ int ita_vitlstm_forward_slots(ita_handle h, const void* image_dev, int image_dty
                               const int* slot_idx_dev, int num_slots, float* output_dev, int batch, void* stream);
 
 /* Arithmetic of the float tail (fusion conv, decoder, LSTM) inside ita_vitlstm_forward:
- *   1 (default)  conv+decoder folded into one matrix at load time, all tail GEMMs on f16 MFMA with
- *                split-precision (hi+lo) operands: within 1e-5 of the f32 graph (task tolerance 1e-4)
+ *   1 (default)  fusion conv, decoder and LSTM layer 0's input projection folded into one matrix at load
+ *                time; all tail GEMMs on f16 MFMA with split-precision (hi+lo) operands: within 1e-5 of the
+ *                f32 graph (task tolerance 1e-4).  The decoder output is never materialised: taps->dec is
+ *                left untouched in this mode.
  *   0            the f32 kernels in the CPU oracle's operation order: equal to the oracle bit for bit.
  * hidden_out_* may alias hidden_in_* in both modes. */
 int ita_set_tail_mode(ita_handle h, int mode);
@@ -129,6 +131,11 @@ int ita_set_tail_mode(ita_handle h, int mode);
  * 5 LSTM + fc.  At most max_forwards calls are recorded (later ones run unprofiled). */
 #define ITA_NUM_STAGES 6
 int ita_profile_begin(ita_handle h, int max_forwards);
+/* Sampled form: only every `every_n`-th forward is instrumented and, when only_stage >= 0, only the two
+ * events around that stage are recorded.  An event in the stream costs a ~5 us pipeline bubble (the next
+ * kernel can no longer be launched under the previous one's tail), so this is what a throughput
+ * measurement uses inside its timed region.  With only_stage = 1 (fused encoder kernel) stage 2 reads 0. */
+int ita_profile_begin_sampled(ita_handle h, int max_forwards, int every_n, int only_stage);
 int ita_profile_end(ita_handle h, double* stage_ms, int* n_forwards);
 
 /* Diagnostic: one encoder layer with in-kernel s_memtime stamps (wave 0 of every workgroup, its

@@ -176,12 +176,14 @@ def test_full_forward_two_steps(torch_cuda, oracle, path, mode):
     ovel0, oh0, oc0, otp = oracle.forward(blob, d["in0.img_u8"], d["in0.desvel"], d["in0.quat"], taps=True)
     for k in ("tokens", "x1", "x2") + (("feat",) if mode == 0 else ()):
         np.testing.assert_array_equal(tp[k].cpu().numpy(), otp[k], err_msg=k)
-    np.testing.assert_allclose(tp["dec"].cpu().numpy(), otp["dec"], atol=tol, rtol=0)
+    if mode == 0:     # in mode 1 the decoder is folded into LSTM layer 0: `dec` is never materialised
+        np.testing.assert_array_equal(tp["dec"].cpu().numpy(), otp["dec"])
     np.testing.assert_allclose(vel0.cpu().numpy(), ovel0, atol=tol, rtol=0)
     np.testing.assert_allclose(h0.cpu().numpy(), oh0, atol=tol, rtol=0)
     np.testing.assert_allclose(c0.cpu().numpy(), oc0, atol=tol, rtol=0)
-    print(f"\n[tail mode {mode}] max|dec - oracle| = {np.abs(tp['dec'].cpu().numpy() - otp['dec']).max():.3e}, "
-          f"max|h - oracle| = {np.abs(h0.cpu().numpy() - oh0).max():.3e}")
+    print(f"\n[tail mode {mode}] max|vel - oracle| = {np.abs(vel0.cpu().numpy() - ovel0).max():.3e}, "
+          f"max|h - oracle| = {np.abs(h0.cpu().numpy() - oh0).max():.3e}, "
+          f"max|c - oracle| = {np.abs(c0.cpu().numpy() - oc0).max():.3e}")
     # second time step, state carried on the device like the reference host carries it
     vel1, (h1, c1) = eng.forward(cu(d["in1.img_u8"]), cu(d["in1.desvel"]), cu(d["in1.quat"]), (h0, c0))
     ovel1, oh1, oc1 = oracle.forward(blob, d["in1.img_u8"], d["in1.desvel"], d["in1.quat"], oh0, oc0)
