@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--image-dtype", choices=["f32", "u8"], default="f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--pipeline", action="store_true", help="two streams: step t+1's image-only front "
+                    "(ita_vitlstm_front) overlaps step t's LSTM back (ita_vitlstm_back); measured gain ~2 %, "
+                    "default is one stream with ita_vitlstm_forward per step")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' only to "
                     "rehearse the N>1 code path with several ranks on one GPU (set ITA_FORCE_DEVICE=0)")
     a = ap.parse_args()
@@ -119,14 +122,39 @@ def main():
         img = (torch.from_numpy(fr["img_u8"]).to(dev).float() / 255.0).contiguous()
     dv, qt = torch.from_numpy(fr["desvel"]).to(dev), torch.from_numpy(fr["quat"]).to(dev)
     state = [(torch.zeros((3, B, 128), device=dev), torch.zeros((3, B, 128), device=dev)) for _ in range(2)]
-    vel = torch.empty((B, 3), device=dev)
+    vels = [torch.empty((B, 3), device=dev) for _ in range(2)]
     gather = itadist.VelocityGather(B, world, dev)
+    pipelined = a.pipeline
+    sf, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    ev_front = [torch.cuda.Event() for _ in range(2)]
+    ev_back = [torch.cuda.Event() for _ in range(2)]
+    started = [False, False]
+    dvf = dv.reshape(B).contiguous()
+    torch.cuda.synchronize()
 
     def step(i):
+        """one time step over this GPU's B streams.  Pipelined form: the image-only front of step i runs on
+        stream sf while the LSTM back of step i-1 is still running on stream sb; the recurrence (back(i) after
+        back(i-1), same stream) and the buffer reuse (front(i) after back(i-2)) are ordered by events."""
         src, dst = state[i & 1], state[(i + 1) & 1]
-        eng.forward(img, dv, qt, src, out=(vel, dst[0], dst[1]))
+        vel = vels[i & 1]
+        if not pipelined:
+            eng.forward(img, dv, qt, src, out=(vel, dst[0], dst[1]))
+            if world > 1:
+                gather.start(vel)
+            return
+        buf = i & 1
+        if started[buf]:
+            sf.wait_event(ev_back[buf])
+        eng.front(img, buf, stream=sf)
+        ev_front[buf].record(sf)
+        sb.wait_event(ev_front[buf])
+        eng.back(dvf, qt, src, (vel, dst[0], dst[1]), buf, stream=sb)
+        ev_back[buf].record(sb)
+        started[buf] = True
         if world > 1:
-            gather.start(vel)
+            with torch.cuda.stream(sb):
+                gather.start(vel)
 
     def fence():
         torch.cuda.synchronize()
@@ -143,7 +171,8 @@ def main():
     NP = 20
     eng.profile_begin(NP)
     for i in range(NP):
-        step(W + i)
+        src, dst = state[(W + i) & 1], state[(W + i + 1) & 1]
+        eng.forward(img, dv, qt, src, out=(vels[0], dst[0], dst[1]))
     gather.finish()
     fence()
     stage_all, n_all = eng.profile_end()
@@ -195,7 +224,8 @@ def main():
             "config": {"workload": "ITAViTLSTM int8 end-to-end forward (BASELINE config 4): 1024 synthetic 60x90 "
                                    "depth frames per GPU per step, LSTM state carried, velocity all-gather",
                        "frames_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                       "image_dtype": a.image_dtype, "weights": "seed-0 synthetic QAT (tests/golden)"},
+                       "image_dtype": a.image_dtype, "weights": "seed-0 synthetic QAT (tests/golden)",
+                       "schedule": "two streams: front(t+1) overlaps back(t)" if pipelined else "one stream"},
             "roofline": roof, "stages": stages,
             "stages_note": "per-stage times from an untimed 20-step pass with events around every stage (each event "
                            "costs a ~5 us stream bubble, so they sum to more than ms_per_step)",

@@ -173,7 +173,7 @@ int ensure_workspace(ita_context* c, int B) {
   HIPCHK(hipMalloc(&c->c1_lo, 2 * (size_t)B * 256));
   HIPCHK(hipMalloc(&c->c2_hi, 2 * (size_t)B * 256));
   HIPCHK(hipMalloc(&c->c2_lo, 2 * (size_t)B * 256));
-  HIPCHK(hipMalloc(&c->part, sizeof(float) * (size_t)NSPLIT * B * 512));
+  HIPCHK(hipMalloc(&c->part, 2 * sizeof(float) * (size_t)NSPLIT * B * 512));   // two buffers: ita_vitlstm_front/back
   c->cap = B;
   return ITA_OK;
 }
@@ -791,6 +791,79 @@ int ita_vitlstm_forward(ita_handle h, const void* image, int image_dtype, const 
                         const float* h_in, const float* c_in, float* vel, float* h_out, float* c_out, int batch,
                         const ita_forward_taps* taps, void* stream) {
   return forward_impl(h, image, image_dtype, desvel, quat, h_in, c_in, vel, h_out, c_out, batch, taps, stream, nullptr, 0);
+}
+
+// ---- two-stage form for software pipelining across time steps -------------------------------------
+int ita_vitlstm_front(ita_handle h, const void* image, int image_dtype, int batch, int buf, void* stream) {
+  int rc = check(h, batch);
+  if (rc) return rc;
+  if (!image || (buf != 0 && buf != 1)) return fail(ITA_ERR_INVALID_ARG, "null image or buf not in {0,1}");
+  if (image_dtype != ITA_IMAGE_F32 && image_dtype != ITA_IMAGE_U8) return fail(ITA_ERR_INVALID_ARG, "bad image dtype");
+  if (!(h->tail_mode == 1 && h->folded)) return fail(ITA_ERR_UNSUPPORTED, "front/back form needs tail mode 1 and a full ITAViTLSTM blob");
+  if ((rc = ensure_workspace(h, batch))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  // sampled single-stage profiling (ita_profile_begin_sampled with only_stage 0, 1 or 3) also works here
+  const int L2 = 2 * h->hdr.num_layers, per = 5 + L2;
+  hipEvent_t* ev = nullptr;
+  if (h->prof && h->prof_stage >= 0 && h->prof_n < h->prof_max && (h->prof_calls++ % h->prof_every) == 0)
+    ev = &h->prof_ev[(size_t)h->prof_n * per];
+  auto mark = [&](int stage, bool end) -> int {
+    if (ev && h->prof_stage == stage) {
+      const int lo[ITA_NUM_STAGES] = {0, 1, 1, 1 + L2, 2 + L2, 3 + L2}, hi[ITA_NUM_STAGES] = {1, 1 + L2, 1 + L2, 2 + L2, 3 + L2, 4 + L2};
+      HIPCHK(hipEventRecord(ev[end ? hi[stage] : lo[stage]], s));
+    }
+    return ITA_OK;
+  };
+  if ((rc = mark(0, false))) return rc;
+  if ((rc = launch_tokenizer(h, image, image_dtype, h->bufA, batch, s))) return rc;
+  if ((rc = mark(0, true)) || (rc = mark(1, false))) return rc;
+  for (int l = 0; l < h->hdr.num_layers; ++l) {
+    const bool last = l == h->hdr.num_layers - 1;
+    if ((rc = launch_encoder(h, l, h->bufA, last ? nullptr : h->bufA, last ? h->x2_hi : nullptr, last ? h->x2_lo : nullptr,
+                             nullptr, batch, s))) return rc;
+  }
+  if ((rc = mark(1, true)) || (rc = mark(3, false))) return rc;
+  float* part = h->part + (size_t)buf * NSPLIT * h->cap * 512;
+  if ((rc = launch_gemm_split<128, 128, 2, 4>(h->x2_hi, h->x2_lo, LDFOLD, h->fold_hi, h->fold_lo, LDFOLD, part, batch, 512,
+                                              KFOLD, NSPLIT, s))) return rc;
+  if ((rc = mark(3, true))) return rc;
+  if (ev && (h->prof_stage == 0 || h->prof_stage == 1 || h->prof_stage == 3)) ++h->prof_n;
+  return ITA_OK;
+}
+
+int ita_vitlstm_back(ita_handle h, const float* desvel, const float* quat, const float* h_in, const float* c_in, float* vel,
+                     float* h_out, float* c_out, int batch, int buf, void* stream) {
+  int rc = check(h, batch);
+  if (rc) return rc;
+  if (!desvel || !quat || !h_in || !c_in || !vel || !h_out || !c_out || (buf != 0 && buf != 1))
+    return fail(ITA_ERR_INVALID_ARG, "null pointer or buf not in {0,1}");
+  if (!(h->tail_mode == 1 && h->folded)) return fail(ITA_ERR_UNSUPPORTED, "front/back form needs tail mode 1 and a full ITAViTLSTM blob");
+  if (batch > h->cap) return fail(ITA_ERR_INVALID_ARG, "ita_vitlstm_front has not run for this batch size");
+  hipStream_t s = (hipStream_t)stream;
+  const int B = batch;
+  const size_t lstride = (size_t)B * 128;
+  const float* part = h->part + (size_t)buf * NSPLIT * h->cap * 512;
+  // layer 0 reads whole rows of h while other workgroups overwrite parts of them when h_out aliases h_in
+  HIPCHK(hipMemcpyAsync(h->gates, h_in, sizeof(float) * lstride, hipMemcpyDeviceToDevice, s));
+  {
+    ItaLstm0Args p{part, NSPLIT, h->fold_inv_scale, h->lw_hi[0], h->lw_lo[0], h->lw_inv_scale[0], h->fold_bias, desvel, quat,
+                   h->gates, c_in, h_out, c_out, h->c1_hi, h->c1_lo, h_in + lstride, B, nullptr};
+    hipLaunchKernelGGL(ita_lstm0_kernel<NSPLIT>, dim3(16, (B + 31) / 32), dim3(64), 0, s, p);
+    HIPCHK(hipGetLastError());
+  }
+  _Float16* chi[3] = {nullptr, h->c1_hi, h->c2_hi};
+  _Float16* clo[3] = {nullptr, h->c1_lo, h->c2_lo};
+  for (int l = 1; l < 3; ++l) {
+    ItaLstmLayerArgs p{chi[l], clo[l], 256, h->lw_hi[l], h->lw_lo[l], 256, h->lw_inv_scale[l], h->bsum[l],
+                       c_in + l * lstride, h_out + l * lstride, c_out + l * lstride, l < 2 ? chi[l + 1] : nullptr,
+                       l < 2 ? clo[l + 1] : nullptr, l < 2 ? h_in + (l + 1) * lstride : nullptr, B, 256, nullptr};
+    hipLaunchKernelGGL(ita_lstm_layer_kernel<4>, dim3(16, (B + 31) / 32), dim3(256), 0, s, p);
+    HIPCHK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(ita_fc_kernel, dim3((B * 3 + 63) / 64), dim3(64), 0, s, h_out + 2 * lstride, h->fc_w, h->fc_b, vel, B,
+                     (const int*)nullptr);
+  HIPCHK(hipGetLastError());
+  return ITA_OK;
 }
 
 int ita_vitlstm_forward_slots(ita_handle h, const void* image, int image_dtype, const float* desvel, const float* quat,

@@ -32,7 +32,8 @@ EXPORTED_SYMBOLS = (
     "ita_last_error", "ita_error_string", "ita_mha_int8", "ita_mha_int8_taps", "ita_ffn_int8", "ita_ffn_int8_taps",
     "ita_encoder_layer", "ita_tokenizer", "ita_fusion_tail", "ita_vitlstm_forward", "ita_bind_dispatch",
     "ita_profile_begin", "ita_profile_begin_sampled", "ita_profile_end", "ita_set_tail_mode", "ita_debug_encoder_stamps",
-    "ita_wire_unpack_packet", "ita_wire_postprocess", "ita_vitlstm_forward_slots",
+    "ita_wire_unpack_packet", "ita_wire_postprocess", "ita_vitlstm_forward_slots", "ita_vitlstm_front",
+    "ita_vitlstm_back",
     "ITASelfAttention_workgroup", "ITASelfAttention_workgroup_expanded", "ITAFeedForward_workgroup",
 )
 
@@ -111,6 +112,8 @@ def lib():
         L.ita_fusion_tail.argtypes = [vp, vp, vp, i, vp]
         L.ita_vitlstm_forward.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, vp, vp, i, C.POINTER(_FwdTaps), vp]
         L.ita_vitlstm_forward_slots.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, i, vp, i, vp]
+        L.ita_vitlstm_front.argtypes = [vp, vp, i, i, i, vp]
+        L.ita_vitlstm_back.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp]
         L.ita_bind_dispatch.argtypes = [vp, i, i]
         L.ita_wire_unpack_packet.argtypes = [vp, C.c_size_t, i, vp]
         L.ita_wire_postprocess.argtypes = [vp, C.c_float, C.c_float, vp]
@@ -315,6 +318,21 @@ class Engine:
         n = C.c_int()
         _chk(lib().ita_profile_end(self._h, ms, C.byref(n)))
         return dict(zip(self.STAGES, list(ms))), n.value
+
+    def front(self, img, buf: int, stream=None):
+        """image-only half of a time step (tokenizer, encoder, folded GEMM) into internal buffer `buf`"""
+        img, dt = self._image(img)
+        sp = _stream_ptr() if stream is None else C.c_void_p(stream.cuda_stream)
+        _chk(lib().ita_vitlstm_front(self._h, img.data_ptr(), dt, img.shape[0], buf, sp))
+        return img.shape[0]
+
+    def back(self, desvel, quat, hidden, out, buf: int, stream=None):
+        """state half of a time step (LSTM + fc) from buffer `buf`; out = (vel, h_out, c_out) tensors"""
+        B = out[0].shape[0]
+        sp = _stream_ptr() if stream is None else C.c_void_p(stream.cuda_stream)
+        _chk(lib().ita_vitlstm_back(self._h, desvel.data_ptr(), quat.data_ptr(), hidden[0].data_ptr(),
+                                    hidden[1].data_ptr(), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), B,
+                                    buf, sp))
 
     def forward_slots(self, img, desvel, quat, state_h, state_c, slot_idx):
         """Serving form: state_h/state_c (3, num_slots, 128) persistent, updated in place for the

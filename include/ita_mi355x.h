@@ -105,6 +105,18 @@ int ita_vitlstm_forward(ita_handle h, const void* image_dev, int image_dtype, co
                         float* output_dev, float* hidden_out_h_dev, float* hidden_out_c_dev, int batch,
                         const ita_forward_taps* taps, void* stream);
 
+/* The same graph cut in two, for software pipelining ACROSS time steps.  A time step's image-only part
+ * (tokenizer, encoder, folded tail GEMM) does not depend on the LSTM state, so step t+1's front can run on
+ * one stream while step t's back (LSTM layers + fc, small latency-bound kernels) runs on another:
+ *     front(t)  on stream F: image -> gate partials in internal buffer `buf` (0 or 1)
+ *     back(t)   on stream B: partials[buf] + (h, c) -> velocity, new (h, c); must wait for front(t)
+ * The caller orders them with events: back(t) after front(t); front(t+2) after back(t) (it reuses
+ * buffer t%2).  front + back on one stream equals ita_vitlstm_forward.  Needs tail mode 1. */
+int ita_vitlstm_front(ita_handle h, const void* image_dev, int image_dtype, int batch, int buf, void* stream);
+int ita_vitlstm_back(ita_handle h, const float* additional_data_dev, const float* quat_data_dev,
+                     const float* hidden_in_h_dev, const float* hidden_in_c_dev, float* output_dev,
+                     float* hidden_out_h_dev, float* hidden_out_c_dev, int batch, int buf, void* stream);
+
 /* Serving form of the same graph: the LSTM state of `num_slots` independent streams lives in two
  * persistent device arrays state_h / state_c of shape (3, num_slots, 128); frame b of the batch belongs to
  * stream slot_idx[b] (device int array, all distinct within one call) and updates that stream's state

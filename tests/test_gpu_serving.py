@@ -92,3 +92,45 @@ def test_udp_server_end_to_end(oracle):
         finally:
             if srv.poll() is None:
                 srv.kill()
+
+
+def test_front_back_pipeline_equals_forward():
+    """five time steps through ita_vitlstm_front / _back on two streams (front(t+1) overlapping back(t),
+    ordered by events) give exactly what five plain ita_vitlstm_forward calls give."""
+    import torch
+    eng = host.Engine(_blob(), device=0)
+    B, T = 64, 5
+    cu = lambda a: torch.from_numpy(a).cuda()
+    frames = [synth.frames(400 + t, B) for t in range(T)]
+    imgs = [cu(f["img_u8"]) for f in frames]
+    dvs, qts = [cu(f["desvel"]) for f in frames], [cu(f["quat"]) for f in frames]
+    # reference: single-stream forwards
+    hid = (torch.zeros((3, B, 128), device="cuda"), torch.zeros((3, B, 128), device="cuda"))
+    ref = []
+    for t in range(T):
+        v, hid = eng.forward(imgs[t], dvs[t], qts[t], hid)
+        ref.append((v.clone(), hid[0].clone(), hid[1].clone()))
+    torch.cuda.synchronize()
+    sf, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    evf, evb = [torch.cuda.Event() for _ in range(2)], [torch.cuda.Event() for _ in range(2)]
+    state = [(torch.zeros((3, B, 128), device="cuda"), torch.zeros((3, B, 128), device="cuda")) for _ in range(2)]
+    outs = [torch.empty((B, 3), device="cuda") for _ in range(T)]
+    hs = []
+    torch.cuda.synchronize()
+    for t in range(T):
+        buf = t & 1
+        if t >= 2:
+            sf.wait_event(evb[buf])
+        eng.front(imgs[t], buf, stream=sf)
+        evf[buf].record(sf)
+        sb.wait_event(evf[buf])
+        src, dst = state[t & 1], state[(t + 1) & 1]
+        eng.back(dvs[t].reshape(B), qts[t], src, (outs[t], dst[0], dst[1]), buf, stream=sb)
+        evb[buf].record(sb)
+        with torch.cuda.stream(sb):
+            hs.append((dst[0].clone(), dst[1].clone()))
+    torch.cuda.synchronize()
+    for t in range(T):
+        assert torch.equal(outs[t], ref[t][0]), t
+        assert torch.equal(hs[t][0], ref[t][1]) and torch.equal(hs[t][1], ref[t][2]), t
+    eng.close()
