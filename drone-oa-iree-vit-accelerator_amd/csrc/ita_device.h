@@ -84,18 +84,45 @@ __device__ __forceinline__ float rq_clamped(int acc, float mult, float lo) {
   return __builtin_amdgcn_fmed3f((float)acc * mult, lo, 127.0f);
 }
 // requantise + pack a 16-accumulator fragment: pk[g] = bytes of acc[4g .. 4g+3]
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// f[i] = clamp(float(acc[i]) * mult, lo, 127) for N accumulators.  Non-packed VALU issues one
+// wave-instruction per 4 cycles per SIMD on gfx950; v_pk_mul_f32 does two multiplies in that slot, so the
+// scale step is written on float2 values.
+template <int N, typename ACC>
+__device__ __forceinline__ void scale_clamp(const ACC& acc, float mult, float lo, float (&f)[N]) {
+  const f32x2 m2 = {mult, mult};
+#pragma unroll
+  for (int i = 0; i < N; i += 2) {
+    f32x2 v = {(float)acc[i], (float)acc[i + 1]};
+    v = v * m2;
+    f[i] = __builtin_amdgcn_fmed3f(v.x, lo, 127.0f);
+    f[i + 1] = __builtin_amdgcn_fmed3f(v.y, lo, 127.0f);
+  }
+}
 template <typename ACC>
 __device__ __forceinline__ void rq_pack16(const ACC& acc, float mult, float lo, unsigned (&pk)[4]) {
   float f[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) f[i] = rq_clamped(acc[i], mult, lo);
+  scale_clamp<16>(acc, mult, lo, f);
   round_pack16(f, pk);
+}
+// sum of the four signed bytes of each of four packed dwords (v_dot4_i32_i8 against 0x01010101)
+__device__ __forceinline__ int sum_bytes16(const unsigned (&pk)[4]) {
+  int s = 0;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) s = __builtin_amdgcn_sdot4((int)pk[g], 0x01010101, s, false);
+  return s;
 }
 // torch.quantize_per_tensor on sixteen floats
 __device__ __forceinline__ void q_pack16(const float* x, float inv_scale, unsigned (&pk)[4]) {
   float f[16];
+  const f32x2 m2 = {inv_scale, inv_scale};
 #pragma unroll
-  for (int i = 0; i < 16; ++i) f[i] = __builtin_amdgcn_fmed3f(x[i] * inv_scale, -128.0f, 127.0f);
+  for (int i = 0; i < 16; i += 2) {
+    f32x2 v = {x[i], x[i + 1]};
+    v = v * m2;
+    f[i] = __builtin_amdgcn_fmed3f(v.x, -128.0f, 127.0f);
+    f[i + 1] = __builtin_amdgcn_fmed3f(v.y, -128.0f, 127.0f);
+  }
   round_pack16(f, pk);
 }
 

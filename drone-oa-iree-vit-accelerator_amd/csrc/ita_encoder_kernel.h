@@ -212,18 +212,17 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
             const i32x4 wb = lds_frag(lds + L::WV, cm_off(d, 32 * ks + 16 * h, P));
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa, wb, acc, 0, 0, 0);
           }
-          // column sum of the requantised V codes (for the unsigned-probability offset): the sum of
-          // the 16 magic-biased bit patterns minus 16 * magic (integer arithmetic wraps harmlessly)
-          unsigned bsum = 0;
+          // acc[4g+i] <-> key tt*32 + 8g + 4h + i, feature d; keys are stored permuted inside each
+          // 64-key block (see ita_int8_kernels.h).  The column sum of the requantised V codes (for the
+          // unsigned-probability offset) is a byte dot product of the packed result.
+          unsigned p4[4];
+          rq_pack16(acc, a.mv, -128.0f, p4);
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const unsigned b0 = rq_bits(acc[4 * g], a.mv), b1 = rq_bits(acc[4 * g + 1], a.mv),
-                           b2 = rq_bits(acc[4 * g + 2], a.mv), b3 = rq_bits(acc[4 * g + 3], a.mv);
-            bsum += (b0 + b1) + (b2 + b3);
             const int kb = tt >> 1, kq = 2 * (g & 1) + h, t = 2 * (tt & 1) + (g >> 1);
-            *(unsigned*)(lds + L::VT + (((kb * 4 + kq) * P + d) << 4) + 4 * t) = pack4(b0, b1, b2, b3);
+            *(unsigned*)(lds + L::VT + (((kb * 4 + kq) * P + d) << 4) + 4 * t) = p4[g];
           }
-          int csum = (int)(bsum - 16u * (unsigned)ITA_MAGIC_I);
+          int csum = sum_bytes16(p4);
           csum += xor32_i(csum);
           if (h == 0) atomicAdd(&colsum[d], csum);
         }
@@ -261,8 +260,10 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
           const i32x4 kf = lds_frag(lds + L::K, cm_off(kt * 16 + qi, 64 * ks + 16 * kq, 128));
           acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf, qf[ks], acc, 0, 0, 0);
         }
+        float lf[4];
+        scale_clamp<4>(acc, a.ml, -128.0f, lf);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[4 * kt + i] = (int)rq_bits(acc[i], a.ml);   // magic-biased: order and differences are preserved
+        for (int i = 0; i < 4; ++i) v[4 * kt + i] = (int)__float_as_uint(lf[i] + ITA_MAGIC_F);   // magic-biased: order and differences are preserved
       }
       int m = v[0];
 #pragma unroll
