@@ -153,11 +153,12 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
   }
   // this wave's out_proj / fc2 output tile is the same for every frame: features et*32.., tokens tt*32..
   const int et = wave >> 2, tt = wave & 3;
-  i32x4 wo_f[6], w2_f[8];
+  // out_proj fragments stay in registers for the whole launch; the fc2 fragments (32 VGPRs) are
+  // re-fetched from L2 every frame at the top of phase L1 and are dead again after phase F2, which keeps
+  // them out of the register-critical attention phase.
+  i32x4 wo_f[6];
 #pragma unroll
   for (int ks = 0; ks < 6; ++ks) wo_f[ks] = gl_frag(a.wo + (size_t)(et * 32 + r) * P + 32 * ks + 16 * h);
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) w2_f[ks] = gl_frag(a.w2 + (size_t)(et * 32 + r) * F + 32 * ks + 16 * h);
 
   float xr[EC];
   if ((int)blockIdx.x < a.B) {
@@ -190,42 +191,76 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
     lds_barrier();
     ITA_STAMP(1);
 
-    // ---------------- phase P: Q, K, V projections
+    // ---------------- phase P: Q, K, V projections.  Each wave owns token tile tt and nine feature tiles
+    // (waves 0-3: Q0-5, K0-2; waves 4-7: K3-5, V0-5), processed TWO AT A TIME: both tiles' fragment reads
+    // and MFMAs are issued before either epilogue, so the VALU-heavy requantisation of one tile overlaps
+    // the LDS/MFMA latency of the other (the wave has only one SIMD partner to hide latency behind).
     {
-      const int half = wave >> 2;
-      for (int ft = 9 * half; ft < 9 * half + 9; ++ft) {
-        const int mat = ft / 6, dt = ft - 6 * mat;
-        if (mat < 2) {
-          const i32x16 acc = tile_wlds_x<E, P>(lds + (mat == 0 ? L::WQ : L::WK), dt * 32, mat == 0 ? l_bq : l_bk,
-                                               lds + L::XQ, tt * 32, lane);
-          store_tile_fx<true>(acc, mat == 0 ? a.mq : a.mk, -128.0f, lds + (mat == 0 ? L::Q : L::K), 0, dt * 32,
-                              tt * 32, lane, nullptr, 0);
-        } else {
-          const int d = dt * 32 + r;
-          const int bias_d = l_bv[d];
-          i32x16 acc;
+      auto qk_acc = [&](int mat, int dt) {
+        return tile_wlds_x<E, P>(lds + (mat == 0 ? L::WQ : L::WK), dt * 32, mat == 0 ? l_bq : l_bk, lds + L::XQ,
+                                 tt * 32, lane);
+      };
+      auto qk_store = [&](const i32x16& acc, int mat, int dt) {
+        store_tile_fx<true>(acc, mat == 0 ? a.mq : a.mk, -128.0f, lds + (mat == 0 ? L::Q : L::K), 0, dt * 32, tt * 32,
+                            lane, nullptr, 0);
+      };
+      auto v_acc = [&](int dt) {
+        const int d = dt * 32 + r;
+        const int bias_d = l_bv[d];
+        i32x16 acc;
 #pragma unroll
-          for (int i = 0; i < 16; ++i) acc[i] = bias_d;
+        for (int i = 0; i < 16; ++i) acc[i] = bias_d;
 #pragma unroll
-          for (int ks = 0; ks < E / 32; ++ks) {
-            const i32x4 xa = lds_frag(lds + L::XQ, cm_off(tt * 32 + r, 32 * ks + 16 * h, 128));
-            const i32x4 wb = lds_frag(lds + L::WV, cm_off(d, 32 * ks + 16 * h, P));
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa, wb, acc, 0, 0, 0);
-          }
-          // acc[4g+i] <-> key tt*32 + 8g + 4h + i, feature d; keys are stored permuted inside each
-          // 64-key block (see ita_int8_kernels.h).  The column sum of the requantised V codes (for the
-          // unsigned-probability offset) is a byte dot product of the packed result.
-          unsigned p4[4];
-          rq_pack16(acc, a.mv, -128.0f, p4);
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int kb = tt >> 1, kq = 2 * (g & 1) + h, t = 2 * (tt & 1) + (g >> 1);
-            *(unsigned*)(lds + L::VT + (((kb * 4 + kq) * P + d) << 4) + 4 * t) = p4[g];
-          }
-          int csum = sum_bytes16(p4);
-          csum += xor32_i(csum);
-          if (h == 0) atomicAdd(&colsum[d], csum);
+        for (int ks = 0; ks < E / 32; ++ks) {
+          const i32x4 xa = lds_frag(lds + L::XQ, cm_off(tt * 32 + r, 32 * ks + 16 * h, 128));
+          const i32x4 wb = lds_frag(lds + L::WV, cm_off(d, 32 * ks + 16 * h, P));
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa, wb, acc, 0, 0, 0);
         }
+        return acc;
+      };
+      auto v_store = [&](const i32x16& acc, int dt) {
+        // acc[4g+i] <-> key tt*32 + 8g + 4h + i, feature d; keys are stored permuted inside each 64-key
+        // block (ita_int8_kernels.h).  The column sum of the requantised V codes (for the
+        // unsigned-probability offset) is a byte dot product of the packed result.
+        const int d = dt * 32 + r;
+        unsigned p4[4];
+        rq_pack16(acc, a.mv, -128.0f, p4);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int kb = tt >> 1, kq = 2 * (g & 1) + h, t = 2 * (tt & 1) + (g >> 1);
+          *(unsigned*)(lds + L::VT + (((kb * 4 + kq) * P + d) << 4) + 4 * t) = p4[g];
+        }
+        int csum = sum_bytes16(p4);
+        csum += xor32_i(csum);
+        if (h == 0) atomicAdd(&colsum[d], csum);
+      };
+      if (wave < 4) {
+#pragma unroll 1
+        for (int ft = 0; ft < 8; ft += 2) {          // (Q0,Q1) (Q2,Q3) (Q4,Q5) (K0,K1)
+          const int m0 = ft / 6, d0 = ft - 6 * m0, m1 = (ft + 1) / 6, d1 = ft + 1 - 6 * m1;
+          const i32x16 a0 = qk_acc(m0, d0), a1 = qk_acc(m1, d1);
+          qk_store(a0, m0, d0);
+          qk_store(a1, m1, d1);
+        }
+        qk_store(qk_acc(1, 2), 1, 2);                 // K2
+      } else {
+        {
+          const i32x16 a0 = qk_acc(1, 3), a1 = qk_acc(1, 4);
+          qk_store(a0, 1, 3);
+          qk_store(a1, 1, 4);
+        }
+        {
+          const i32x16 a0 = qk_acc(1, 5), a1 = v_acc(0);
+          qk_store(a0, 1, 5);
+          v_store(a1, 0);
+        }
+#pragma unroll 1
+        for (int dt = 1; dt < 5; dt += 2) {
+          const i32x16 a0 = v_acc(dt), a1 = v_acc(dt + 1);
+          v_store(a0, dt);
+          v_store(a1, dt + 1);
+        }
+        v_store(v_acc(5), 5);
       }
     }
     lds_barrier();
@@ -325,6 +360,13 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
     ITA_STAMP(4);
 
     // ---------------- phase L1: x1 = LN1(x + dequant(out_q)); quantise x1 for the FFN in place
+    i32x4 w2_f[8];
+    {
+      const int8_t* w2p = a.w2 + (size_t)(et * 32 + r) * F + 16 * h;
+      asm volatile("" : "+v"(w2p));   // opaque per frame: keeps the loads inside the loop
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) w2_f[ks] = gl_frag(w2p + 32 * ks);
+    }
     float x1[EC];
     {
       const i32x4 pk = *(const i32x4*)(lds + L::XQ + cm_off(token, qtr * EC, 128));
@@ -347,9 +389,12 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
     ITA_STAMP(5);
 
     // ---------------- phase F1: fc1 + ReLU -> hidden (chunk-major over the dead K / V^T images)
-    for (int ft = (wave >> 2) * 4; ft < (wave >> 2) * 4 + 4; ++ft) {
-      const i32x16 acc = tile_wlds_x<E, F>(lds + L::W1, ft * 32, l_b1, lds + L::XQ, tt * 32, lane);
-      store_tile_fx<true>(acc, a.m1, 0.0f, lds + L::H, 0, ft * 32, tt * 32, lane, nullptr, 0);
+#pragma unroll 1
+    for (int ft = (wave >> 2) * 4; ft < (wave >> 2) * 4 + 4; ft += 2) {   // two tiles in flight, as in phase P
+      const i32x16 a0 = tile_wlds_x<E, F>(lds + L::W1, ft * 32, l_b1, lds + L::XQ, tt * 32, lane);
+      const i32x16 a1 = tile_wlds_x<E, F>(lds + L::W1, (ft + 1) * 32, l_b1, lds + L::XQ, tt * 32, lane);
+      store_tile_fx<true>(a0, a.m1, 0.0f, lds + L::H, 0, ft * 32, tt * 32, lane, nullptr, 0);
+      store_tile_fx<true>(a1, a.m1, 0.0f, lds + L::H, 0, (ft + 1) * 32, tt * 32, lane, nullptr, 0);
     }
     lds_barrier();
     ITA_STAMP(6);
