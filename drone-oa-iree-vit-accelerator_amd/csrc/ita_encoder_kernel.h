@@ -232,7 +232,7 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
         }
         int csum = sum_bytes16(p4);
         csum += xor32_i(csum);
-        if (h == 0) atomicAdd(&colsum[d], csum);
+        if (h == 0) atomicAdd(&colsum[d], csum << 7);   // kept pre-multiplied by the 128 offset
       };
       if (wave < 4) {
 #pragma unroll 1
@@ -330,15 +330,16 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
 #pragma unroll
         for (int di = 0; di < 4; ++di) {
           const int dt = 4 * dg + di;
-          i32x4 acc = *(const i32x4*)(colsum + dt * 16 + 4 * kq);
-          acc = acc << 7;
+          i32x4 acc = *(const i32x4*)(colsum + dt * 16 + 4 * kq);   // 128 * column sum
 #pragma unroll
           for (int kb = 0; kb < 2; ++kb) {
             const i32x4 vf = lds_frag(lds + L::VT, ((((kb * 4 + kq) * P) + dt * 16 + qi) << 4));
             acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pf[kb], acc, 0, 0, 0);
           }
+          float t4[4];
+          scale_clamp<4>(acc, a.mc, -128.0f, t4);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) cf[4 * di + i] = rq_clamped(acc[i], a.mc, -128.0f);
+          for (int i = 0; i < 4; ++i) cf[4 * di + i] = t4[i];
         }
         unsigned c4[4];
         round_pack16(cf, c4);
