@@ -286,7 +286,11 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
       i32x4 qf[3];
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) qf[ks] = lds_frag(lds + L::Q, cm_off(q0 + qi, 64 * ks + 16 * kq, 128));
-      int v[32];
+      // logits as packed signed 16-bit pairs: the whole integer softmax below then runs on v_pk_*_16
+      // instructions, two keys per VALU op.  w[2kt + j] = {logit 4kt+2j, logit 4kt+2j+1}.
+      typedef short s16x2 __attribute__((ext_vector_type(2)));
+      typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+      s16x2 w[16];
 #pragma unroll
       for (int kt = 0; kt < 8; ++kt) {
         i32x4 acc = {0, 0, 0, 0};
@@ -297,32 +301,43 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
         }
         float lf[4];
         scale_clamp<4>(acc, a.ml, -128.0f, lf);
+        unsigned bi[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[4 * kt + i] = (int)__float_as_uint(lf[i] + ITA_MAGIC_F);   // magic-biased: order and differences are preserved
+        for (int i = 0; i < 4; ++i) bi[i] = __float_as_uint(lf[i] + ITA_MAGIC_F);   // low 16 bits = rne(logit), two's complement
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          w[2 * kt + j] = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(bi[2 * j + 1], bi[2 * j], 0x05040100u));
       }
-      int m = v[0];
+      s16x2 m2 = w[0];
 #pragma unroll
-      for (int j = 1; j < 32; ++j) m = max(m, v[j]);
+      for (int j = 1; j < 16; ++j) m2 = __builtin_elementwise_max(m2, w[j]);
+      int m = max((int)m2.x, (int)m2.y);
       m = max(m, xor16_i(m));
       m = max(m, xor32_i(m));
-      int sum = 0;
+      const s16x2 mm = {(short)m, (short)m};
+      const s16x2 cap = {15, 15};                  // 256 >> s and inv_hi >> s are both 0 from s = 9 on
+      const u16x2 one = {256, 256};
+      u16x2 sh[16], sum2 = {0, 0};
 #pragma unroll
-      for (int j = 0; j < 32; ++j) {
-        v[j] = min(m - v[j], 23);
-        sum += 256 >> v[j];
+      for (int j = 0; j < 16; ++j) {
+        sh[j] = __builtin_bit_cast(u16x2, __builtin_elementwise_min((s16x2)(mm - w[j]), cap));
+        sum2 += one >> sh[j];
       }
+      int sum = (int)sum2.x + (int)sum2.y;         // <= 16 * 256 per half: no 16-bit overflow
       sum += xor16_i(sum);
       sum += xor32_i(sum);
       sum = max(sum, 1);
-      const int inv_hi = ((int)floorf((1.0f / (float)sum) * 16711680.0f)) >> 8;
+      const int inv_hi = ((int)floorf((1.0f / (float)sum) * 16711680.0f)) >> 8;   // <= 255: sum >= 256
+      const u16x2 iv = {(unsigned short)inv_hi, (unsigned short)inv_hi};
       i32x4 pf[2];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int kt = 4 * kb + t;
-          pf[kb][t] = (int)(pack4(inv_hi >> v[4 * kt], inv_hi >> v[4 * kt + 1], inv_hi >> v[4 * kt + 2],
-                                  inv_hi >> v[4 * kt + 3]) ^ 0x80808080u);
+          const unsigned p01 = __builtin_bit_cast(unsigned, (u16x2)(iv >> sh[2 * kt]));
+          const unsigned p23 = __builtin_bit_cast(unsigned, (u16x2)(iv >> sh[2 * kt + 1]));
+          pf[kb][t] = (int)(__builtin_amdgcn_perm(p23, p01, 0x06040200u) ^ 0x80808080u);
         }
 #pragma unroll
       for (int dg = 0; dg < 3; ++dg) {          // four 16-feature tiles at a time: 16 values per lane
