@@ -7,15 +7,16 @@
 // Same arithmetic, bit for bit, as ita_mha_kernel + ita_ffn_kernel (ita_int8_kernels.h); what
 // changes is where the operands live, because those two kernels are bound by the latency of
 // their global weight loads, not by MFMA or VALU issue:
-//   * persistent workgroups (one per CU) keep Wq/Wk/Wv/W1 and all biases in LDS as chunk-major
-//     int8 images for the whole launch; every wave always computes the same out_proj / fc2 output
-//     tile, so its Wo / W2 fragments stay in registers (24 + 32 VGPRs);
+//   * persistent workgroups (one per CU) keep Wq/Wk/Wv/W1/W2 and all biases in LDS as chunk-major
+//     int8 images for the whole launch; every wave always computes the same out_proj output tile,
+//     so its Wo fragments stay in registers (24 VGPRs);
 //   * x1 never leaves the CU: LayerNorm1's result stays in the registers of the thread that
 //     quantises it for the FFN;
 //   * the next frame's tokens are fetched into registers while the current frame is in the
 //     attention phase.
 // LDS: x_q/out_q 8 KB | Q(ctx) 24 KB | K 24 KB | V^T 24 KB (K..V^T reused for the 32 KB FFN hidden
-// layer) | colsum | Wq Wk Wv 36 KB | W1 16 KB | biases 3.75 KB  = 140 032 B of the CU's 160 KB.
+// layer) | colsum | Wq Wk Wv 36 KB | W1 16 KB | W2 16 KB | biases 3.75 KB | LN 1 KB = 157 184 B of the
+// CU's 160 KB.
 #pragma once
 #include "ita_int8_kernels.h"
 
@@ -54,7 +55,8 @@ struct ItaEncLds {
   static constexpr int WK = WQ + P * E;
   static constexpr int WV = WK + P * E;
   static constexpr int W1 = WV + P * E;           // int8 [4][256][16]
-  static constexpr int BIAS = W1 + F * E;         // int32: bq 192 | bk 192 | bv 192 | bo 64 | b1 256 | b2 64
+  static constexpr int W2 = W1 + F * E;           // int8 [16][64][16]
+  static constexpr int BIAS = W2 + E * F;         // int32: bq 192 | bk 192 | bv 192 | bo 64 | b1 256 | b2 64
   static constexpr int LNP = BIAS + (3 * P + E + F + E) * 4;   // f32: n1w | n1b | n2w | n2b (64 each)
   static constexpr int TOTAL = LNP + 4 * E * 4;
 };
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
   load_weight_cm<E, P>(a.wk, lds + L::WK, tid);
   load_weight_cm<E, P>(a.wv, lds + L::WV, tid);
   load_weight_cm<E, F>(a.w1, lds + L::W1, tid);
+  load_weight_cm<F, E>(a.w2, lds + L::W2, tid);
   for (int i = tid; i < 3 * P + E + F + E; i += 512) {
     int v;
     if (i < P) v = a.bq[i];
@@ -153,9 +156,7 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
   }
   // this wave's out_proj / fc2 output tile is the same for every frame: features et*32.., tokens tt*32..
   const int et = wave >> 2, tt = wave & 3;
-  // out_proj fragments stay in registers for the whole launch; the fc2 fragments (32 VGPRs) are
-  // re-fetched from L2 every frame at the top of phase L1 and are dead again after phase F2, which keeps
-  // them out of the register-critical attention phase.
+  // its out_proj fragments stay in registers for the whole launch (there is no LDS left for Wo)
   i32x4 wo_f[6];
 #pragma unroll
   for (int ks = 0; ks < 6; ++ks) wo_f[ks] = gl_frag(a.wo + (size_t)(et * 32 + r) * P + 32 * ks + 16 * h);
@@ -376,13 +377,6 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
     ITA_STAMP(4);
 
     // ---------------- phase L1: x1 = LN1(x + dequant(out_q)); quantise x1 for the FFN in place
-    i32x4 w2_f[8];
-    {
-      const int8_t* w2p = a.w2 + (size_t)(et * 32 + r) * F + 16 * h;
-      asm volatile("" : "+v"(w2p));   // opaque per frame: keeps the loads inside the loop
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) w2_f[ks] = gl_frag(w2p + 32 * ks);
-    }
     float x1[EC];
     {
       const i32x4 pk = *(const i32x4*)(lds + L::XQ + cm_off(token, qtr * EC, 128));
@@ -415,9 +409,9 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
     lds_barrier();
     ITA_STAMP(6);
 
-    // ---------------- phase F2: fc2, weights in registers -> out_q (over the FFN's x_q)
+    // ---------------- phase F2: fc2 -> out_q (over the FFN's x_q)
     {
-      const i32x16 acc = tile_wreg_x<8>(w2_f, l_b2, et * 32, lds + L::H, tt * 32, lane);
+      const i32x16 acc = tile_wlds_x<F, E>(lds + L::W2, et * 32, l_b2, lds + L::H, tt * 32, lane);
       store_tile_fx<true>(acc, a.m2, -128.0f, lds + L::XQ, 0, et * 32, tt * 32, lane, nullptr, 0);
     }
     lds_barrier();

@@ -684,6 +684,10 @@ static int forward_impl(ita_handle h, const void* image, int image_dtype, const 
   const bool fast = h->tail_mode == 1 && h->folded;
   if (slots && !fast) return fail(ITA_ERR_UNSUPPORTED, "slot-indexed state needs tail mode 1");
   const size_t lstride = (size_t)(slots ? state_rows : batch) * 128;   // layer stride of the (3, rows, 128) state
+  // Layer 0 of the LSTM reads whole rows of h while other workgroups write parts of the same rows when the
+  // state is updated in place (slot-indexed state, or hidden_out_h aliasing hidden_in_h): only then is the
+  // layer-0 h staged by frame index (a side copy inside the encoder kernel).
+  const bool stage_h0 = slots || (h_out < h_in + lstride && h_in < h_out + lstride);
   const int ev_per_fwd = 5 + 2 * h->hdr.num_layers;
   hipEvent_t* ev = nullptr;
   if (h->prof && h->prof_n < h->prof_max && (h->prof_calls++ % h->prof_every) == 0)
@@ -707,8 +711,8 @@ static int forward_impl(ita_handle h, const void* image, int image_dtype, const 
     float* yout = (planes && !(taps && taps->x2)) ? nullptr : h->bufA;
     if (h->hdr.E == 64) {     // fused encoder layer, in place on bufA
       if ((rc = launch_encoder(h, l, h->bufA, yout, planes ? h->x2_hi : nullptr, planes ? h->x2_lo : nullptr,
-                               (taps && last) ? taps->x1 : nullptr, B, s, nullptr, planes ? h_in : nullptr,
-                               planes ? h->gates : nullptr, slots))) return rc;
+                               (taps && last) ? taps->x1 : nullptr, B, s, nullptr, (planes && stage_h0) ? h_in : nullptr,
+                               (planes && stage_h0) ? h->gates : nullptr, slots))) return rc;
       MARK();
       MARK();
     } else {
@@ -735,7 +739,7 @@ static int forward_impl(ita_handle h, const void* image, int image_dtype, const 
     _Float16* clo[3] = {nullptr, h->c1_lo, h->c2_lo};
     {
       ItaLstm0Args p{h->part, NSPLIT, h->fold_inv_scale, h->lw_hi[0], h->lw_lo[0], h->lw_inv_scale[0], h->fold_bias,
-                     desvel, quat, h->gates /* staged h_in0, by frame */, c_in, h_out, c_out, chi[1], clo[1],
+                     desvel, quat, stage_h0 ? h->gates /* staged by frame */ : h_in, c_in, h_out, c_out, chi[1], clo[1],
                      h_in + lstride, B, slots};
       hipLaunchKernelGGL(ita_lstm0_kernel<NSPLIT>, dim3(16, (B + 31) / 32), dim3(64), 0, s, p);
       HIPCHK(hipGetLastError());
