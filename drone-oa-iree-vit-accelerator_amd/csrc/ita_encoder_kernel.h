@@ -63,24 +63,29 @@ struct ItaEncLds {
 static_assert(ItaEncLds::H + 128 * 256 <= ItaEncLds::COLSUM, "FFN hidden layer must fit in the K + V^T region");
 static_assert(ItaEncLds::TOTAL <= 160 * 1024, "LDS budget");
 
-// weights [ROWS][KB] row-major in global -> chunk-major LDS image.  All loads are issued before
-// the first LDS store so that the memory latency is paid once, not once per piece.
+// weights [ROWS][KB] row-major in global -> chunk-major LDS image, in two steps so that the caller can
+// issue the loads of ALL matrices before the first LDS store: the memory latency is paid once per
+// workgroup, not once per matrix.
 template <int KB, int ROWS>
-__device__ __forceinline__ void load_weight_cm(const int8_t* __restrict__ w, char* dst, int tid) {
-  constexpr int CH = KB / 16, NP = ROWS * CH, N = (NP + 511) / 512;
+struct ItaWeightStage {
+  static constexpr int CH = KB / 16, NP = ROWS * CH, N = (NP + 511) / 512;
   i32x4 v[N];
+  __device__ __forceinline__ void fetch(const int8_t* __restrict__ w, int tid) {
 #pragma unroll
-  for (int j = 0; j < N; ++j) {
-    const int p = tid + 512 * j;
-    v[j] = (i32x4){0, 0, 0, 0};
-    if (p < NP) v[j] = *(const i32x4*)(w + (size_t)p * 16);
+    for (int j = 0; j < N; ++j) {
+      const int p = tid + 512 * j;
+      v[j] = (i32x4){0, 0, 0, 0};
+      if (p < NP) v[j] = *(const i32x4*)(w + (size_t)p * 16);
+    }
   }
+  __device__ __forceinline__ void put(char* dst, int tid) const {
 #pragma unroll
-  for (int j = 0; j < N; ++j) {
-    const int p = tid + 512 * j, row = p / CH, ch = p - row * CH;
-    if (p < NP) *(i32x4*)(dst + ((ch * ROWS + row) << 4)) = v[j];
+    for (int j = 0; j < N; ++j) {
+      const int p = tid + 512 * j, row = p / CH, ch = p - row * CH;
+      if (p < NP) *(i32x4*)(dst + ((ch * ROWS + row) << 4)) = v[j];
+    }
   }
-}
+};
 
 // 32x32 tile: A = weights from a chunk-major LDS image (WROWS rows), Bt = activations (128 rows)
 template <int KB, int WROWS>
@@ -133,42 +138,53 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
   const int *l_bq = bias, *l_bk = bias + P, *l_bv = bias + 2 * P, *l_bo = bias + 3 * P, *l_b1 = bias + 3 * P + E,
             *l_b2 = bias + 3 * P + E + F;
 
-  // ---- once per workgroup: weights and biases
-  load_weight_cm<E, P>(a.wq, lds + L::WQ, tid);
-  load_weight_cm<E, P>(a.wk, lds + L::WK, tid);
-  load_weight_cm<E, P>(a.wv, lds + L::WV, tid);
-  load_weight_cm<E, F>(a.w1, lds + L::W1, tid);
-  load_weight_cm<F, E>(a.w2, lds + L::W2, tid);
-  for (int i = tid; i < 3 * P + E + F + E; i += 512) {
-    int v;
-    if (i < P) v = a.bq[i];
-    else if (i < 2 * P) v = a.bk[i - P];
-    else if (i < 3 * P) v = a.bv[i - 2 * P];
-    else if (i < 3 * P + E) v = a.bo[i - 3 * P];
-    else if (i < 3 * P + E + F) v = a.b1[i - 3 * P - E];
-    else v = a.b2[i - 3 * P - E - F];
-    bias[i] = v;
-  }
+  // ---- once per workgroup: weights, biases, LayerNorm parameters, this wave's out_proj fragments and
+  // the first frame's tokens -- every global load is issued before the first wait
+  const int et = wave >> 2, tt = wave & 3;   // out_proj / fc2 output tile of this wave: features et*32.., tokens tt*32..
   float* lnp = (float*)(lds + L::LNP);
-  if (tid < 4 * E) {
-    const int which = tid >> 6, c = tid & 63;
-    lnp[tid] = which == 0 ? a.n1w[c] : which == 1 ? a.n1b[c] : which == 2 ? a.n2w[c] : a.n2b[c];
-  }
-  // this wave's out_proj / fc2 output tile is the same for every frame: features et*32.., tokens tt*32..
-  const int et = wave >> 2, tt = wave & 3;
-  // its out_proj fragments stay in registers for the whole launch (there is no LDS left for Wo)
-  i32x4 wo_f[6];
-#pragma unroll
-  for (int ks = 0; ks < 6; ++ks) wo_f[ks] = gl_frag(a.wo + (size_t)(et * 32 + r) * P + 32 * ks + 16 * h);
-
+  i32x4 wo_f[6];                             // (there is no LDS left for Wo: its fragments live in registers)
   float xr[EC];
-  if ((int)blockIdx.x < a.B) {
-    const float* xrow = a.x + ((size_t)blockIdx.x * S + token) * E + qtr * EC;
+  {
+    ItaWeightStage<E, P> sq, sk, sv;
+    ItaWeightStage<E, F> s1;
+    ItaWeightStage<F, E> s2;
+    sq.fetch(a.wq, tid); sk.fetch(a.wk, tid); sv.fetch(a.wv, tid); s1.fetch(a.w1, tid); s2.fetch(a.w2, tid);
+    constexpr int NB = 3 * P + E + F + E;
+    int bv[2];
 #pragma unroll
-    for (int i = 0; i < EC; i += 4) {
-      const f32x4 v = *(const f32x4*)(xrow + i);
-      xr[i] = v.x; xr[i + 1] = v.y; xr[i + 2] = v.z; xr[i + 3] = v.w;
+    for (int j = 0; j < 2; ++j) {
+      const int i = tid + 512 * j;
+      int v = 0;
+      if (i < P) v = a.bq[i];
+      else if (i < 2 * P) v = a.bk[i - P];
+      else if (i < 3 * P) v = a.bv[i - 2 * P];
+      else if (i < 3 * P + E) v = a.bo[i - 3 * P];
+      else if (i < 3 * P + E + F) v = a.b1[i - 3 * P - E];
+      else if (i < NB) v = a.b2[i - 3 * P - E - F];
+      bv[j] = v;
     }
+    float lv = 0.0f;
+    if (tid < 4 * E) {
+      const int which = tid >> 6, c = tid & 63;
+      lv = which == 0 ? a.n1w[c] : which == 1 ? a.n1b[c] : which == 2 ? a.n2w[c] : a.n2b[c];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) wo_f[ks] = gl_frag(a.wo + (size_t)(et * 32 + r) * P + 32 * ks + 16 * h);
+    if ((int)blockIdx.x < a.B) {
+      const float* xrow = a.x + ((size_t)blockIdx.x * S + token) * E + qtr * EC;
+#pragma unroll
+      for (int i = 0; i < EC; i += 4) {
+        const f32x4 v = *(const f32x4*)(xrow + i);
+        xr[i] = v.x; xr[i + 1] = v.y; xr[i + 2] = v.z; xr[i + 3] = v.w;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    sq.put(lds + L::WQ, tid); sk.put(lds + L::WK, tid); sv.put(lds + L::WV, tid); s1.put(lds + L::W1, tid);
+    s2.put(lds + L::W2, tid);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (tid + 512 * j < NB) bias[tid + 512 * j] = bv[j];
+    if (tid < 4 * E) lnp[tid] = lv;
   }
 
   int fi = 0;
@@ -267,19 +283,12 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
     lds_barrier();
     ITA_STAMP(2);
 
-    // prefetch the next frame's tokens; they are consumed at the next phase 0
+    // prefetch of the next frame's tokens (consumed at the next phase 0): the four 16-byte loads are
+    // spread over the logits loop below -- eight waves issuing them back to back would each sit at the
+    // head of the CU's address path (64 B/clk) instead of issuing MFMAs
     float xn[EC];
-    {
-      const int nb = b + gridDim.x;
-      if (nb < a.B) {
-        const float* xrow = a.x + ((size_t)nb * S + token) * E + qtr * EC;
-#pragma unroll
-        for (int i = 0; i < EC; i += 4) {
-          const f32x4 v = *(const f32x4*)(xrow + i);
-          xn[i] = v.x; xn[i + 1] = v.y; xn[i + 2] = v.z; xn[i + 3] = v.w;
-        }
-      }
-    }
+    const int nb = b + gridDim.x;
+    const float* xnrow = a.x + ((size_t)min(nb, a.B - 1) * S + token) * E + qtr * EC;
 
     // ---------------- phase A: 16 queries per wave, logits and probabilities stay in registers
     {
@@ -299,6 +308,11 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
         for (int ks = 0; ks < 3; ++ks) {
           const i32x4 kf = lds_frag(lds + L::K, cm_off(kt * 16 + qi, 64 * ks + 16 * kq, 128));
           acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf, qf[ks], acc, 0, 0, 0);
+        }
+        if ((kt & 1) == 0) {
+          const f32x4 v = *(const f32x4*)(xnrow + 2 * kt);
+          xn[2 * kt] = v.x; xn[2 * kt + 1] = v.y; xn[2 * kt + 2] = v.z; xn[2 * kt + 3] = v.w;
+          __builtin_amdgcn_sched_barrier(0);
         }
         float lf[4];
         scale_clamp<4>(acc, a.ml, -128.0f, lf);
