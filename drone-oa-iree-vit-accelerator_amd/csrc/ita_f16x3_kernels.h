@@ -269,6 +269,12 @@ __global__ __launch_bounds__(64) void ita_lstm0_kernel(const ItaLstm0Args a) {
     wh[s] = *(const f16x8*)(wrow_hi + 16 * s);
     wl[s] = *(const f16x8*)(wrow_lo + 16 * s);
   }
+  // epilogue operands too: everything this lane will ever read is in flight before the first wait
+  const f32x4 ci = *(const f32x4*)(a.c_in + sb * 128 + u0);
+  const f32x4 nh = *(const f32x4*)(a.nx_h_in + sb * 128 + u0);
+  f32x4 bz[4];
+#pragma unroll
+  for (int gt = 0; gt < 4; ++gt) bz[gt] = *(const f32x4*)(a.bias + gt * 128 + u0);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int s = 0; s < 9; ++s) {
@@ -286,7 +292,6 @@ __global__ __launch_bounds__(64) void ita_lstm0_kernel(const ItaLstm0Args a) {
   }
   if (b >= a.B) return;
   // acc[4*gate + q] <-> gate (i,f,g,o), unit u0 + q, frame b
-  const f32x4 ci = *(const f32x4*)(a.c_in + sb * 128 + u0);
   f32x4 hn, cn;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(64) void ita_lstm0_kernel(const ItaLstm0Args a) {
       float ps = pz[0][gt][q];
 #pragma unroll
       for (int z = 1; z < NS; ++z) ps += pz[z][gt][q];
-      g[gt] = (ps * a.inv_fold_scale + acc[4 * gt + q] * a.inv_wscale) + a.bias[gt * 128 + u0 + q];
+      g[gt] = (ps * a.inv_fold_scale + acc[4 * gt + q] * a.inv_wscale) + bz[gt][q];
     }
     const float ig = ita_sigmoid(g[0]), fg = ita_sigmoid(g[1]), cg = ita_tanh(g[2]), og = ita_sigmoid(g[3]);
     const float c = fmaf(fg, ci[q], ig * cg);
@@ -305,7 +310,6 @@ __global__ __launch_bounds__(64) void ita_lstm0_kernel(const ItaLstm0Args a) {
   }
   *(f32x4*)(a.c_out + sb * 128 + u0) = cn;
   *(f32x4*)(a.h_out + sb * 128 + u0) = hn;
-  const f32x4 nh = *(const f32x4*)(a.nx_h_in + sb * 128 + u0);
   f16x4 h_hi, h_lo, n_hi, n_lo;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -359,6 +363,12 @@ __global__ __launch_bounds__(256) void ita_lstm_layer_kernel(const ItaLstmLayerA
     fwl[s] = *(const f16x8*)(a.w_lo + wo + 16 * s);
     fal[s] = *(const f16x8*)(a.a_lo + ao + 16 * s);
   }
+  // epilogue operands of this lane's (frame, unit) as well: wave q finishes unit (4h + q) of frame r
+  const int q = wave, b = f0 + r, u = ut * 8 + 4 * h + q;
+  const size_t sb = a.slots ? (size_t)a.slots[arow] : (size_t)arow;
+  const float c_prev = a.c_in[sb * 128 + u];
+  const float nx_prev = a.nx_hi ? a.nx_h_in[sb * 128 + u] : 0.0f;
+  const float b_i = a.bsum[u], b_f = a.bsum[128 + u], b_g = a.bsum[256 + u], b_o = a.bsum[384 + u];
   __builtin_amdgcn_sched_barrier(0);   // keep every load ahead of the first MFMA (hipcc otherwise sinks them)
   f32x16 acc;
 #pragma unroll
@@ -372,21 +382,18 @@ __global__ __launch_bounds__(256) void ita_lstm_layer_kernel(const ItaLstmLayerA
 #pragma unroll
   for (int e = 0; e < 16; ++e) part[wave][e][lane] = acc[e];
   __syncthreads();
-  // wave q finishes unit (4h + q) of every (frame r): gates e = q, 4+q, 8+q, 12+q
-  const int q = wave, b = f0 + r;
+  // gates e = q, 4+q, 8+q, 12+q of unit (4h + q), frame r
   if (b >= a.B) return;
-  const size_t sb = a.slots ? (size_t)a.slots[b] : (size_t)b;
   float gsum[4];
 #pragma unroll
   for (int gte = 0; gte < 4; ++gte) {
     const int e = 4 * gte + q;
     gsum[gte] = ((part[0][e][lane] + part[1][e][lane]) + part[2][e][lane]) + part[3][e][lane];
   }
-  const int u = ut * 8 + 4 * h + q;
-  const float gi = gsum[0] * a.inv_wscale + a.bsum[u], gf = gsum[1] * a.inv_wscale + a.bsum[128 + u],
-              gg = gsum[2] * a.inv_wscale + a.bsum[256 + u], go = gsum[3] * a.inv_wscale + a.bsum[384 + u];
+  const float gi = gsum[0] * a.inv_wscale + b_i, gf = gsum[1] * a.inv_wscale + b_f,
+              gg = gsum[2] * a.inv_wscale + b_g, go = gsum[3] * a.inv_wscale + b_o;
   const float ig = ita_sigmoid(gi), fg = ita_sigmoid(gf), cg = ita_tanh(gg), og = ita_sigmoid(go);
-  const float c = fmaf(fg, a.c_in[sb * 128 + u], ig * cg);
+  const float c = fmaf(fg, c_prev, ig * cg);
   const float hn = og * ita_tanh(c);
   a.c_out[sb * 128 + u] = c;
   a.h_out[sb * 128 + u] = hn;
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(256) void ita_lstm_layer_kernel(const ItaLstmLayerA
     split_f16(hn, x, y);
     a.nx_hi[(size_t)b * 256 + u] = x;
     a.nx_lo[(size_t)b * 256 + u] = y;
-    split_f16(a.nx_h_in[sb * 128 + u], x, y);
+    split_f16(nx_prev, x, y);
     a.nx_hi[(size_t)b * 256 + 128 + u] = x;
     a.nx_lo[(size_t)b * 256 + 128 + u] = y;
   }
