@@ -171,6 +171,17 @@ __device__ __forceinline__ float ita_expf(float x) {
 __device__ __forceinline__ float ita_sigmoid(float x) { return 1.0f / (1.0f + ita_expf(-x)); }
 __device__ __forceinline__ float ita_tanh(float x) { return 1.0f - 2.0f / (ita_expf(2.0f * x) + 1.0f); }
 
+// source row / column and weight of F.interpolate(mode='bilinear', align_corners=False)
+__device__ __forceinline__ void bilinear_src_dev(int dst, float scale, int in, int& i0, int& ip, float& l1) {
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  if (src < 0.0f) src = 0.0f;
+  int i = (int)src;
+  if (i > in - 1) i = in - 1;
+  i0 = i;
+  ip = (i < in - 1) ? 1 : 0;
+  l1 = src - (float)i;
+}
+
 // LayerNorm over E channels spread over NT adjacent lanes (NT = 2 or 4), each holding EC = E/NT
 // consecutive channels, in the oracle's summation order: 4 blocks of E/4 consecutive channels
 // summed sequentially, combined (p0+p1)+(p2+p3).   r[] is overwritten with the result.

@@ -41,6 +41,11 @@ struct ItaEncArgs {
   const float* h0_src;
   float* h0_dst;
   const int* slots;
+  // fused tokenizer (ita_encoder_kernel<true>): u8 wire frames in, tokens never leave the CU
+  const uint8_t* img;    // (B,60,90) u8
+  const float* tok_w;    // [53][64]: conv weights k-major (rows 0..48), rows 49..51 zero, row 52 = conv bias
+  const float *tok_lnw, *tok_lnb;
+  float* tok_tap;        // optional (B,128,64): the tokens (LayerNorm output of the tokenizer)
 };
 
 struct ItaEncLds {
@@ -58,8 +63,16 @@ struct ItaEncLds {
   static constexpr int W2 = W1 + F * E;           // int8 [16][64][16]
   static constexpr int BIAS = W2 + E * F;         // int32: bq 192 | bk 192 | bv 192 | bo 64 | b1 256 | b2 64
   static constexpr int LNP = BIAS + (3 * P + E + F + E) * 4;   // f32: n1w | n1b | n2w | n2b (64 each)
-  static constexpr int TOTAL = LNP + 4 * E * 4;
+  static constexpr int TLN = LNP + 4 * E * 4;      // f32: tokenizer LayerNorm w | b
+  static constexpr int LUT = TLN + 2 * E * 4;      // f32 [256]: k / 255.0f
+  static constexpr int TOTAL = LUT + 256 * 4;
+  // tokenizer scratch, alive only between two frames, over the dead Q | K | V^T images:
+  static constexpr int TK_IMG = Q;                         // u8 [66][96], zero border
+  static constexpr int TK_WT = TK_IMG + 66 * 96;           // f32 [53][64]
+  static constexpr int TK_WAVE = TK_WT + 53 * 64 * 4;      // per wave: f32 [16][52] patches, then [16][68] pre-LN tokens
+  static constexpr int TK_WAVE_BYTES = 16 * 68 * 4;
 };
+static_assert(ItaEncLds::TK_WAVE + 8 * ItaEncLds::TK_WAVE_BYTES <= ItaEncLds::COLSUM, "tokenizer scratch must fit in Q | K | V^T");
 static_assert(ItaEncLds::H + 128 * 256 <= ItaEncLds::COLSUM, "FFN hidden layer must fit in the K + V^T region");
 static_assert(ItaEncLds::TOTAL <= 160 * 1024, "LDS budget");
 
@@ -126,6 +139,11 @@ __device__ __forceinline__ i32x16 tile_wreg_x(const i32x4 (&wf)[KSTEPS], const i
   return acc;
 }
 
+// TOK: the layer's input is computed in place from u8 wire frames (OverlapPatchMerging, reference
+// models/ITA/QAT/layers.py:39-45; same arithmetic and operation order as ita_tokenizer_kernel) instead of
+// being read from a.x: between two frames the workgroup tokenizes its next frame into the registers that
+// phase 0 quantises -- no token round trip through HBM and one kernel boundary less.
+template <bool TOK>
 __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
   using L = ItaEncLds;
   constexpr int S = 128, E = 64, P = 192, F = 256, EC = 16;
@@ -170,7 +188,10 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
     }
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks) wo_f[ks] = gl_frag(a.wo + (size_t)(et * 32 + r) * P + 32 * ks + 16 * h);
-    if ((int)blockIdx.x < a.B) {
+    float tlv = 0.0f;
+    if constexpr (TOK) {
+      if (tid < 2 * E) tlv = tid < E ? a.tok_lnw[tid] : a.tok_lnb[tid - E];
+    } else if ((int)blockIdx.x < a.B) {
       const float* xrow = a.x + ((size_t)blockIdx.x * S + token) * E + qtr * EC;
 #pragma unroll
       for (int i = 0; i < EC; i += 4) {
@@ -179,12 +200,141 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TOK) {
+      if (tid < 2 * E) ((float*)(lds + L::TLN))[tid] = tlv;
+      if (tid < 256) ((float*)(lds + L::LUT))[tid] = (float)tid / 255.0f;   // the reference host's float(pixel) / 255.0f (main.cpp:168-169)
+    }
     sq.put(lds + L::WQ, tid); sk.put(lds + L::WK, tid); sv.put(lds + L::WV, tid); s1.put(lds + L::W1, tid);
     s2.put(lds + L::W2, tid);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
       if (tid + 512 * j < NB) bias[tid + 512 * j] = bv[j];
     if (tid < 4 * E) lnp[tid] = lv;
+  }
+
+  // ---- fused tokenizer (TOK): fetch = global loads of one frame + the conv weights into registers,
+  // tokenize = those registers -> this thread's 16 channels of its token in xr.
+  i32x4 tk_px = {0, 0, 0, 0}, tk_w[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  auto tok_fetch = [&](int fb) {
+    const uint8_t* src = a.img + (size_t)fb * 5400;
+    tk_px = (i32x4){0, 0, 0, 0};
+    if (tid < 337) tk_px = *(const i32x4*)(src + 16 * tid);
+    else if (tid == 337) { tk_px.x = *(const int*)(src + 5392); tk_px.y = *(const int*)(src + 5396); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (tid + 512 * j < 53 * 16) tk_w[j] = *(const i32x4*)(a.tok_w + 4 * (tid + 512 * j));
+  };
+  auto tokenize = [&](int fb) {
+    uint8_t* img = (uint8_t*)(lds + L::TK_IMG);
+    float* wt = (float*)(lds + L::TK_WT);
+    float* pb = (float*)(lds + L::TK_WAVE + wave * L::TK_WAVE_BYTES);   // [16][52], then [16][68]
+    const float* lut = (const float*)(lds + L::LUT);
+    // everything below is derived from an opaque copy of the thread id: otherwise the compiler hoists the
+    // per-thread geometry (pixel addresses, bilinear weights) out of the frame loop and keeps ~60 registers
+    // alive across the register-critical attention phase
+    int otid = tid;
+    asm volatile("" : "+v"(otid));
+    const int token = otid >> 2, qtr = otid & 3, lane = otid & 63;
+    // T0: zero the frame image (its border stays zero), conv weights -> LDS
+    if (tid < 66 * 96 / 16) *(i32x4*)(img + 16 * tid) = (i32x4){0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (tid + 512 * j < 53 * 16) *(i32x4*)(wt + 4 * (tid + 512 * j)) = tk_w[j];
+    lds_barrier();
+    // T1: 16 consecutive pixels per thread; they span at most two image rows.  Chunk 337 carries eight
+    // pad bytes, zeros that land in the (zero) bottom border.
+    if (otid < 338) {
+      const int y = (16 * otid) / 90, x = 16 * otid - 90 * y, n0 = 90 - x;
+      uint8_t* dst = img + (y + 3) * 96 + x + 3;
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        dst[e + (e >= n0 ? 6 : 0)] = (uint8_t)((unsigned)tk_px[e >> 2] >> (8 * (e & 3)));
+    }
+    lds_barrier();
+    // T2: blended 7x7 patches (conv and bilinear resize are both linear): thread (token, part) takes kernel
+    // rows 2*part, 2*part+1 (part 3: row 6 and the zero pad columns) from a 4 x 9 pixel window
+    {
+      const int part = qtr, tl = token & 15;
+      int y0, yp, x0, xp;
+      float ly, lx;
+      bilinear_src_dev(token >> 4, 30.0f / 8.0f, 30, y0, yp, ly);
+      bilinear_src_dev(token & 15, 45.0f / 16.0f, 45, x0, xp, lx);
+      const float h1 = ly, h0 = 1.0f - ly, w1 = lx, w0 = 1.0f - lx;
+      const uint8_t* win = img + (2 * y0 + 2 * part) * 96 + 2 * x0;   // (-3 conv padding) + (3 border) = 0; even address
+      float f[4][10];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+          const unsigned two = *(const unsigned short*)(win + j * 96 + 2 * c);
+          f[j][2 * c] = lut[two & 0xffu];
+          f[j][2 * c + 1] = lut[two >> 8];
+        }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        if (jj == 0 || part < 3) {
+#pragma unroll
+          for (int kx = 0; kx < 7; ++kx) {
+            const float va = f[jj][kx], vb = xp ? f[jj][kx + 2] : va;
+            const float vc = yp ? f[jj + 2][kx] : va;
+            const float vd = yp ? (xp ? f[jj + 2][kx + 2] : f[jj + 2][kx]) : vb;
+            pb[tl * 52 + (2 * part + jj) * 7 + kx] = h0 * (w0 * va + w1 * vb) + h1 * (w0 * vc + w1 * vd);
+          }
+        }
+      }
+      if (part == 3) { pb[tl * 52 + 49] = 0.0f; pb[tl * 52 + 50] = 0.0f; pb[tl * 52 + 51] = 0.0f; }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the patch rows are private to this wave
+    __builtin_amdgcn_wave_barrier();
+    // T3: tokens[16 x 64] = bias + patches[16 x 52] . wt[52 x 64] on v_mfma_f32_16x16x4_f32, on gfx950 an
+    // exact ascending-k fmaf chain -- the oracle's order
+    {
+      const int col = lane & 15, kq = lane >> 4;
+      f32x4 acc[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const float bv = wt[52 * 64 + ct * 16 + col];
+        acc[ct] = (f32x4){bv, bv, bv, bv};
+      }
+#pragma unroll
+      for (int s = 0; s < 13; ++s) {
+        const float av = pb[col * 52 + 4 * s + kq];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wt[(4 * s + kq) * 64 + ct * 16 + col], acc[ct], 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();
+      // C layout: col = channel ct*16 + (lane&15), row = token 4*(lane>>4) + i  -> pre[token][68] over the patches
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pb[(4 * kq + i) * 68 + ct * 16 + col] = acc[ct][i];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    // T4: LayerNorm of this thread's 16 channels of its token
+    {
+      const float* pre = pb + (token & 15) * 68 + qtr * EC;
+#pragma unroll
+      for (int i = 0; i < EC; i += 4) {
+        const f32x4 v = *(const f32x4*)(pre + i);
+        xr[i] = v.x; xr[i + 1] = v.y; xr[i + 2] = v.z; xr[i + 3] = v.w;
+      }
+      const float* tln = (const float*)(lds + L::TLN);
+      layernorm_lanes<E, 4>(xr, tln, tln + E, qtr * EC);
+      if (a.tok_tap) {
+        float* o = a.tok_tap + ((size_t)fb * S + token) * E + qtr * EC;
+#pragma unroll
+        for (int i = 0; i < EC; i += 4) *(f32x4*)(o + i) = (f32x4){xr[i], xr[i + 1], xr[i + 2], xr[i + 3]};
+      }
+    }
+  };
+  if constexpr (TOK) {
+    lds_barrier();   // LUT and LayerNorm parameters are in place
+    if ((int)blockIdx.x < a.B) {
+      tok_fetch(blockIdx.x);
+      tokenize(blockIdx.x);
+    }
   }
 
   int fi = 0;
@@ -288,7 +438,7 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
     // head of the CU's address path (64 B/clk) instead of issuing MFMAs
     float xn[EC];
     const int nb = b + gridDim.x;
-    const float* xnrow = a.x + ((size_t)min(nb, a.B - 1) * S + token) * E + qtr * EC;
+    const float* xnrow = TOK ? nullptr : a.x + ((size_t)min(nb, a.B - 1) * S + token) * E + qtr * EC;
 
     // ---------------- phase A: 16 queries per wave, logits and probabilities stay in registers
     {
@@ -309,7 +459,7 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
           const i32x4 kf = lds_frag(lds + L::K, cm_off(kt * 16 + qi, 64 * ks + 16 * kq, 128));
           acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf, qf[ks], acc, 0, 0, 0);
         }
-        if ((kt & 1) == 0) {
+        if (!TOK && (kt & 1) == 0) {
           const f32x4 v = *(const f32x4*)(xnrow + 2 * kt);
           xn[2 * kt] = v.x; xn[2 * kt + 1] = v.y; xn[2 * kt + 2] = v.z; xn[2 * kt + 3] = v.w;
           __builtin_amdgcn_sched_barrier(0);
@@ -391,6 +541,9 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
     ITA_STAMP(4);
 
     // ---------------- phase L1: x1 = LN1(x + dequant(out_q)); quantise x1 for the FFN in place
+    if constexpr (TOK) {
+      if (nb < a.B) tok_fetch(nb);   // next frame's pixels and the conv weights: in flight until phase L2 is over
+    }
     float x1[EC];
     {
       const i32x4 pk = *(const i32x4*)(lds + L::XQ + cm_off(token, qtr * EC, 128));
@@ -464,8 +617,13 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
       }
     }
     ITA_STAMP(8);
+    if constexpr (TOK) {
+      // the Q | K | V^T images are dead since the barrier after phase F2: the tokenizer's scratch
+      if (nb < a.B) tokenize(nb);
+    } else {
 #pragma unroll
-    for (int i = 0; i < EC; ++i) xr[i] = xn[i];
+      for (int i = 0; i < EC; ++i) xr[i] = xn[i];
+    }
     // phase 0 of the next frame writes x_q, which phase L2 above has just read: the read and the
     // write of a given 16-byte slot are by the same thread, so no barrier is needed here
   }

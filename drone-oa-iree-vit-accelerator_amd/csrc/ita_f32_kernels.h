@@ -29,16 +29,6 @@ struct ItaTokArgs {
   int dbg;            // diagnostic bit mask: 1 skip image fill, 2 skip blend, 4 skip MFMA, 8 skip LN/store
 };
 
-__device__ __forceinline__ void bilinear_src_dev(int dst, float scale, int in, int& i0, int& ip, float& l1) {
-  float src = scale * ((float)dst + 0.5f) - 0.5f;
-  if (src < 0.0f) src = 0.0f;
-  int i = (int)src;
-  if (i > in - 1) i = in - 1;
-  i0 = i;
-  ip = (i < in - 1) ? 1 : 0;
-  l1 = src - (float)i;
-}
-
 // Layout of one workgroup (256 threads = 4 waves, wave w owns tokens 32w..32w+31):
 //   img  [66][96] f32   frame with zero border                                  (all waves)
 //   wt   [50][E]  f32   conv weights k-major, row 49 = 0                         (all waves)

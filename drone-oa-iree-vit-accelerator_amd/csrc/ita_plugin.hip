@@ -67,6 +67,7 @@ struct ita_context {
   // derived device buffers
   float* tail_wT = nullptr;
   float* tok_wT = nullptr;                 // [50][E] conv7x7 weights k-major, row 49 = 0
+  float* tok_w16 = nullptr;                // [53][64] for the tokenizer fused into the encoder: rows 49..51 = 0, row 52 = conv bias
   float* wcat[3] = {nullptr, nullptr, nullptr};
   float* bsum[3] = {nullptr, nullptr, nullptr};
   // split-precision (f16 hi/lo) tail: folded tail+decoder matrix and LSTM weights, pre-scaled
@@ -122,6 +123,8 @@ void free_weights(ita_context* c) {
   if (c->tail_wT) (void)hipFree(c->tail_wT);
   if (c->tok_wT) (void)hipFree(c->tok_wT);
   c->tok_wT = nullptr;
+  if (c->tok_w16) (void)hipFree(c->tok_w16);
+  c->tok_w16 = nullptr;
   for (int l = 0; l < 3; ++l) {
     if (c->wcat[l]) (void)hipFree(c->wcat[l]);
     if (c->bsum[l]) (void)hipFree(c->bsum[l]);
@@ -246,7 +249,8 @@ int launch_ffn(ita_context* c, int layer, const float* x, float* y, int B, bool 
 // whole encoder layer in one launch (E = 64)
 int launch_encoder(ita_context* c, int layer, const float* x, float* y, _Float16* y_hi, _Float16* y_lo, float* x1_tap,
                    int B, hipStream_t s, unsigned long long* stamps = nullptr, const float* h0_src = nullptr,
-                   float* h0_dst = nullptr, const int* slots = nullptr) {
+                   float* h0_dst = nullptr, const int* slots = nullptr, const void* img_u8 = nullptr,
+                   float* tok_tap = nullptr) {
   const Layer& L = c->layers[layer];
   if (!L.n1w || !L.n2w) return fail(ITA_ERR_BAD_BLOB, "LayerNorm parameters missing from the blob");
   ItaEncArgs a{};
@@ -262,9 +266,22 @@ int launch_encoder(ita_context* c, int layer, const float* x, float* y, _Float16
   a.stamps = stamps;
   a.h0_src = h0_src; a.h0_dst = h0_dst; a.slots = slots;
   const int grid = B < c->num_cus ? B : c->num_cus;
-  hipLaunchKernelGGL(ita_encoder_kernel, dim3(grid), dim3(512), ItaEncLds::TOTAL, s, a);
+  if (img_u8) {   // tokenizer fused in front (u8 wire frames): x is not read
+    if (!c->tok_w16 || !c->tok_lw || !c->tok_lb) return fail(ITA_ERR_BAD_BLOB, "tokenizer parameters missing from the blob");
+    a.img = (const uint8_t*)img_u8; a.tok_w = c->tok_w16; a.tok_lnw = c->tok_lw; a.tok_lnb = c->tok_lb; a.tok_tap = tok_tap;
+    hipLaunchKernelGGL(ita_encoder_kernel<true>, dim3(grid), dim3(512), ItaEncLds::TOTAL, s, a);
+  } else {
+    hipLaunchKernelGGL(ita_encoder_kernel<false>, dim3(grid), dim3(512), ItaEncLds::TOTAL, s, a);
+  }
   HIPCHK(hipGetLastError());
   return ITA_OK;
+}
+
+// u8 wire frames into the E = 64 model: the tokenizer runs inside the first encoder layer's kernel
+// (ITA_SPLIT_TOKENIZER=1 keeps the separate ita_tokenizer_kernel launch, for comparison)
+bool fuse_tokenizer(const ita_context* c, int image_dtype) {
+  static const bool split = getenv("ITA_SPLIT_TOKENIZER") != nullptr;
+  return !split && image_dtype == ITA_IMAGE_U8 && c->hdr.E == 64 && c->tok_w16;
 }
 
 int launch_tokenizer(ita_context* c, const void* img, int dtype, float* tokens, int B, hipStream_t s) {
@@ -444,7 +461,8 @@ int ita_create(ita_handle* out, int device_ordinal) {
   if ((rc = set_lds(ita_tokenizer_kernel<128, true>, ita_tok_lds_bytes<128>()))) { delete c; return rc; }
   if ((rc = set_lds(ita_tokenizer_kernel<128, false>, ita_tok_lds_bytes<128>()))) { delete c; return rc; }
   if ((rc = set_lds(ita_tail_kernel<64>, ita_tail_lds_bytes<64>()))) { delete c; return rc; }
-  if ((rc = set_lds(ita_encoder_kernel, ItaEncLds::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_encoder_kernel<false>, ItaEncLds::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_encoder_kernel<true>, ItaEncLds::TOTAL))) { delete c; return rc; }
   {
     auto k1 = ita_gemm_f16x3_kernel<128, 128, 2, 4>;
     auto k1r = ita_gemm_f16x3_kernel<128, 128, 2, 4, true>;
@@ -539,6 +557,14 @@ int ita_load_weights(ita_handle h, const void* blob, size_t nbytes) {
       for (int k = 0; k < 49; ++k) wT[(size_t)k * Ei + c] = cw[(size_t)c * 49 + k];
     HIPCHK(hipMalloc(&h->tok_wT, wT.size() * sizeof(float)));
     HIPCHK(hipMemcpy(h->tok_wT, wT.data(), wT.size() * sizeof(float), hipMemcpyHostToDevice));
+    const float* cb = hptr<float>(h, "tok.conv_b");
+    if (Ei == 64 && cb) {
+      std::vector<float> w16((size_t)53 * 64, 0.0f);
+      memcpy(w16.data(), wT.data(), sizeof(float) * 49 * 64);
+      memcpy(&w16[(size_t)52 * 64], cb, sizeof(float) * 64);
+      HIPCHK(hipMalloc(&h->tok_w16, w16.size() * sizeof(float)));
+      HIPCHK(hipMemcpy(h->tok_w16, w16.data(), w16.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
   }
   // derived: conv3x3 weights re-laid [c][ky][kx][o -> 12] so one tap's 9 output weights are contiguous
   if (const float* cw = hptr<float>(h, "tail.conv_w")) {
@@ -702,9 +728,10 @@ static int forward_impl(ita_handle h, const void* image, int image_dtype, const 
   }
 #define MARK() do { if (ev && (h->prof_stage < 0 || evi == m_lo || evi == m_hi)) HIPCHK(hipEventRecord(ev[evi], s)); ++evi; } while (0)
   MARK();
-  if ((rc = launch_tokenizer(h, image, image_dtype, h->bufA, B, s))) return rc;
+  const bool fused_tok = fuse_tokenizer(h, image_dtype);
+  if (!fused_tok && (rc = launch_tokenizer(h, image, image_dtype, h->bufA, B, s))) return rc;
   MARK();
-  if (taps && taps->tokens) HIPCHK(hipMemcpyAsync(taps->tokens, h->bufA, tokb, hipMemcpyDeviceToDevice, s));
+  if (!fused_tok && taps && taps->tokens) HIPCHK(hipMemcpyAsync(taps->tokens, h->bufA, tokb, hipMemcpyDeviceToDevice, s));
   for (int l = 0; l < h->hdr.num_layers; ++l) {
     const bool last = l == h->hdr.num_layers - 1;
     const bool planes = fast && last;
@@ -712,7 +739,8 @@ static int forward_impl(ita_handle h, const void* image, int image_dtype, const 
     if (h->hdr.E == 64) {     // fused encoder layer, in place on bufA
       if ((rc = launch_encoder(h, l, h->bufA, yout, planes ? h->x2_hi : nullptr, planes ? h->x2_lo : nullptr,
                                (taps && last) ? taps->x1 : nullptr, B, s, nullptr, (planes && stage_h0) ? h_in : nullptr,
-                               (planes && stage_h0) ? h->gates : nullptr, slots))) return rc;
+                               (planes && stage_h0) ? h->gates : nullptr, slots, (fused_tok && l == 0) ? image : nullptr,
+                               (fused_tok && l == 0 && taps) ? taps->tokens : nullptr))) return rc;
       MARK();
       MARK();
     } else {
@@ -819,12 +847,13 @@ int ita_vitlstm_front(ita_handle h, const void* image, int image_dtype, int batc
     return ITA_OK;
   };
   if ((rc = mark(0, false))) return rc;
-  if ((rc = launch_tokenizer(h, image, image_dtype, h->bufA, batch, s))) return rc;
+  const bool fused_tok = fuse_tokenizer(h, image_dtype);
+  if (!fused_tok && (rc = launch_tokenizer(h, image, image_dtype, h->bufA, batch, s))) return rc;
   if ((rc = mark(0, true)) || (rc = mark(1, false))) return rc;
   for (int l = 0; l < h->hdr.num_layers; ++l) {
     const bool last = l == h->hdr.num_layers - 1;
     if ((rc = launch_encoder(h, l, h->bufA, last ? nullptr : h->bufA, last ? h->x2_hi : nullptr, last ? h->x2_lo : nullptr,
-                             nullptr, batch, s))) return rc;
+                             nullptr, batch, s, nullptr, nullptr, nullptr, nullptr, (fused_tok && l == 0) ? image : nullptr))) return rc;
   }
   if ((rc = mark(1, true)) || (rc = mark(3, false))) return rc;
   float* part = h->part + (size_t)buf * NSPLIT * h->cap * 512;
