@@ -32,8 +32,8 @@ struct ItaEncArgs {
   float f_inv_sx, m1, m2, s2;                    // FFN scalars
   const float *n1w, *n1b, *n2w, *n2b;
   int B;
-  // diagnostic only (null in production): wave 0 of each workgroup stores s_memtime at the 10 phase
-  // boundaries of its first 8 frames: stamps[(block * 8 + frame) * 10 + phase]
+  // diagnostic only (null in production): wave 0 of each workgroup stores s_memtime at the phase
+  // boundaries of its first 8 frames: stamps[(block * 8 + frame) * 16 + slot] (ita_mi355x.h)
   unsigned long long* stamps;
   // optional side copy for the LSTM that follows: layer-0 hidden state of frame b (row slots[b] or b of
   // h0_src) -> h0_dst[b].  Layer 0 reads whole rows of h while other workgroups overwrite parts of the
@@ -67,8 +67,8 @@ struct ItaEncLds {
   static constexpr int LUT = TLN + 2 * E * 4;      // f32 [256]: k / 255.0f
   static constexpr int TOTAL = LUT + 256 * 4;
   // tokenizer scratch, alive only between two frames, over the dead Q | K | V^T images:
-  static constexpr int TK_IMG = Q;                         // u8 [66][96], zero border
-  static constexpr int TK_WT = TK_IMG + 66 * 96;           // f32 [53][64]
+  static constexpr int TK_IMG = Q;                         // f32 [66][96] frame / 255 with zero border
+  static constexpr int TK_WT = TK_IMG + 66 * 96 * 4;       // f32 [53][64]
   static constexpr int TK_WAVE = TK_WT + 53 * 64 * 4;      // per wave: f32 [16][52] patches, then [16][68] pre-LN tokens
   static constexpr int TK_WAVE_BYTES = 16 * 68 * 4;
 };
@@ -212,6 +212,11 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
     if (tid < 4 * E) lnp[tid] = lv;
   }
 
+  int fi = 0;
+#define ITA_STAMP(ph)                                                                                   \
+  do {                                                                                                  \
+    if (a.stamps && tid == 0 && fi < 8) a.stamps[((size_t)blockIdx.x * 8 + fi) * 16 + (ph)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
   // ---- fused tokenizer (TOK): fetch = global loads of one frame + the conv weights into registers,
   // tokenize = those registers -> this thread's 16 channels of its token in xr.
   i32x4 tk_px = {0, 0, 0, 0}, tk_w[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -224,33 +229,51 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
     for (int j = 0; j < 2; ++j)
       if (tid + 512 * j < 53 * 16) tk_w[j] = *(const i32x4*)(a.tok_w + 4 * (tid + 512 * j));
   };
-  auto tokenize = [&](int fb) {
-    uint8_t* img = (uint8_t*)(lds + L::TK_IMG);
+  // stage: the prefetched registers -> LDS (frame as f32 through the k/255 table, zero border, conv
+  // weights).  Runs right after the barrier that ends phase F2, BEFORE phase L2 issues its global stores:
+  // consuming the prefetched loads any later would wait on those stores too (one in-order vmcnt).
+  auto tok_stage = [&]() {
+    float* img = (float*)(lds + L::TK_IMG);
     float* wt = (float*)(lds + L::TK_WT);
-    float* pb = (float*)(lds + L::TK_WAVE + wave * L::TK_WAVE_BYTES);   // [16][52], then [16][68]
     const float* lut = (const float*)(lds + L::LUT);
+    int otid = tid;
+    asm volatile("" : "+v"(otid));   // see tok_compute
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (otid + 512 * j < 53 * 16) *(i32x4*)(wt + 4 * (otid + 512 * j)) = tk_w[j];
+    // 936 border cells (rows 0-2, 63-65; columns 0-2, 93-95 of the 60 image rows): disjoint from the pixels
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int bc = otid + 512 * j;
+      if (bc < 936) {
+        int row, col;
+        if (bc < 576) { const int q = bc / 96; row = q < 3 ? q : q + 60; col = bc - 96 * q; }
+        else { const int e = bc - 576, q = e / 6, k = e - 6 * q; row = 3 + q; col = k < 3 ? k : 90 + k; }
+        img[row * 96 + col] = 0.0f;
+      }
+    }
+    // 16 consecutive pixels per thread; they span at most two image rows.  Chunk 337's eight pad bytes
+    // (code 0 -> 0.0f) land in the bottom border.
+    if (otid < 338) {
+      const int y = (16 * otid) / 90, x = 16 * otid - 90 * y, n0 = 90 - x;
+      float* dst = img + (y + 3) * 96 + x + 3;
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        dst[e + (e >= n0 ? 6 : 0)] = lut[((unsigned)tk_px[e >> 2] >> (8 * (e & 3))) & 0xffu];
+    }
+  };
+  auto tok_compute = [&](int fb) {
+    const float* img = (const float*)(lds + L::TK_IMG);
+    const float* wt = (const float*)(lds + L::TK_WT);
+    float* pb = (float*)(lds + L::TK_WAVE + wave * L::TK_WAVE_BYTES);   // [16][52], then [16][68]
     // everything below is derived from an opaque copy of the thread id: otherwise the compiler hoists the
     // per-thread geometry (pixel addresses, bilinear weights) out of the frame loop and keeps ~60 registers
     // alive across the register-critical attention phase
     int otid = tid;
     asm volatile("" : "+v"(otid));
     const int token = otid >> 2, qtr = otid & 3, lane = otid & 63;
-    // T0: zero the frame image (its border stays zero), conv weights -> LDS
-    if (tid < 66 * 96 / 16) *(i32x4*)(img + 16 * tid) = (i32x4){0, 0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      if (tid + 512 * j < 53 * 16) *(i32x4*)(wt + 4 * (tid + 512 * j)) = tk_w[j];
     lds_barrier();
-    // T1: 16 consecutive pixels per thread; they span at most two image rows.  Chunk 337 carries eight
-    // pad bytes, zeros that land in the (zero) bottom border.
-    if (otid < 338) {
-      const int y = (16 * otid) / 90, x = 16 * otid - 90 * y, n0 = 90 - x;
-      uint8_t* dst = img + (y + 3) * 96 + x + 3;
-#pragma unroll
-      for (int e = 0; e < 16; ++e)
-        dst[e + (e >= n0 ? 6 : 0)] = (uint8_t)((unsigned)tk_px[e >> 2] >> (8 * (e & 3)));
-    }
-    lds_barrier();
+    ITA_STAMP(9);
     // T2: blended 7x7 patches (conv and bilinear resize are both linear): thread (token, part) takes kernel
     // rows 2*part, 2*part+1 (part 3: row 6 and the zero pad columns) from a 4 x 9 pixel window
     {
@@ -260,15 +283,15 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
       bilinear_src_dev(token >> 4, 30.0f / 8.0f, 30, y0, yp, ly);
       bilinear_src_dev(token & 15, 45.0f / 16.0f, 45, x0, xp, lx);
       const float h1 = ly, h0 = 1.0f - ly, w1 = lx, w0 = 1.0f - lx;
-      const uint8_t* win = img + (2 * y0 + 2 * part) * 96 + 2 * x0;   // (-3 conv padding) + (3 border) = 0; even address
+      const float* win = img + (2 * y0 + 2 * part) * 96 + 2 * x0;   // (-3 conv padding) + (3 border) = 0; 8-byte aligned
       float f[4][10];
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int c = 0; c < 5; ++c) {
-          const unsigned two = *(const unsigned short*)(win + j * 96 + 2 * c);
-          f[j][2 * c] = lut[two & 0xffu];
-          f[j][2 * c + 1] = lut[two >> 8];
+          const f32x2 two = *(const f32x2*)(win + j * 96 + 2 * c);
+          f[j][2 * c] = two.x;
+          f[j][2 * c + 1] = two.y;
         }
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
@@ -286,6 +309,7 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the patch rows are private to this wave
     __builtin_amdgcn_wave_barrier();
+    ITA_STAMP(10);
     // T3: tokens[16 x 64] = bias + patches[16 x 52] . wt[52 x 64] on v_mfma_f32_16x16x4_f32, on gfx950 an
     // exact ascending-k fmaf chain -- the oracle's order
     {
@@ -312,6 +336,7 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
+    ITA_STAMP(11);
     // T4: LayerNorm of this thread's 16 channels of its token
     {
       const float* pre = pb + (token & 15) * 68 + qtr * EC;
@@ -328,20 +353,17 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
         for (int i = 0; i < EC; i += 4) *(f32x4*)(o + i) = (f32x4){xr[i], xr[i + 1], xr[i + 2], xr[i + 3]};
       }
     }
+    ITA_STAMP(12);
   };
   if constexpr (TOK) {
     lds_barrier();   // LUT and LayerNorm parameters are in place
     if ((int)blockIdx.x < a.B) {
       tok_fetch(blockIdx.x);
-      tokenize(blockIdx.x);
+      tok_stage();
+      tok_compute(blockIdx.x);
     }
   }
 
-  int fi = 0;
-#define ITA_STAMP(ph)                                                                                   \
-  do {                                                                                                  \
-    if (a.stamps && tid == 0 && fi < 8) a.stamps[((size_t)blockIdx.x * 8 + fi) * 10 + (ph)] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
   for (int b = blockIdx.x; b < a.B; b += gridDim.x, ++fi) {
     ITA_STAMP(0);
     // ---------------- phase 0: quantise (xr holds this thread's 16 channels of one token)
@@ -583,6 +605,10 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
     }
     lds_barrier();
     ITA_STAMP(7);
+    if constexpr (TOK) {
+      // the Q | K | V^T images are dead from here on: the tokenizer's scratch
+      if (nb < a.B) tok_stage();
+    }
 
     // ---------------- phase L2: y = LN2(x1 + dequant(out_q))
     {
@@ -618,8 +644,7 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
     }
     ITA_STAMP(8);
     if constexpr (TOK) {
-      // the Q | K | V^T images are dead since the barrier after phase F2: the tokenizer's scratch
-      if (nb < a.B) tokenize(nb);
+      if (nb < a.B) tok_compute(nb);
     } else {
 #pragma unroll
       for (int i = 0; i < EC; ++i) xr[i] = xn[i];

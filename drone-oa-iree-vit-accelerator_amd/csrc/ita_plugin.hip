@@ -669,13 +669,14 @@ int ita_encoder_layer(ita_handle h, int layer, const float* x, float* y, int bat
   return launch_ffn(h, layer, y, y, batch, true, nullptr, (hipStream_t)stream);
 }
 
-int ita_debug_encoder_stamps(ita_handle h, int layer, const float* x, float* y, int batch, unsigned long long* stamps,
-                             void* stream) {
+int ita_debug_encoder_stamps(ita_handle h, int layer, const float* x, const void* image_u8, float* y, int batch,
+                             unsigned long long* stamps, void* stream) {
   int rc = check(h, batch);
   if (rc) return rc;
-  if (!x || !y || !stamps || layer < 0 || layer >= h->hdr.num_layers || h->hdr.E != 64)
+  if ((!x && !image_u8) || !y || !stamps || layer < 0 || layer >= h->hdr.num_layers || h->hdr.E != 64)
     return fail(ITA_ERR_INVALID_ARG, "bad argument");
-  return launch_encoder(h, layer, x, y, nullptr, nullptr, nullptr, batch, (hipStream_t)stream, stamps);
+  return launch_encoder(h, layer, x, y, nullptr, nullptr, nullptr, batch, (hipStream_t)stream, stamps, nullptr, nullptr,
+                        nullptr, image_u8);
 }
 
 int ita_tokenizer(ita_handle h, const void* image, int image_dtype, float* tokens, int batch, void* stream) {

@@ -119,7 +119,7 @@ def lib():
         L.ita_wire_postprocess.argtypes = [vp, C.c_float, C.c_float, vp]
         L.ita_wire_postprocess.restype = None
         L.ita_set_tail_mode.argtypes = [vp, i]
-        L.ita_debug_encoder_stamps.argtypes = [vp, i, vp, vp, i, vp, vp]
+        L.ita_debug_encoder_stamps.argtypes = [vp, i, vp, vp, vp, i, vp, vp]
         L.ita_profile_begin.argtypes = [vp, i]
         L.ita_profile_begin_sampled.argtypes = [vp, i, i, i]
         L.ita_profile_end.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i)]
@@ -290,13 +290,19 @@ class Engine:
         return vel, (h_out, c_out)
 
     def encoder_stamps(self, x, layer: int = 0):
-        """diagnostic: per-phase s_memtime stamps of the fused encoder kernel -> int64 [blocks, 8, 10]"""
+        """diagnostic: per-phase s_memtime stamps of the fused encoder kernel -> int64 [blocks, 8, 16].
+        x: (B,128,64) f32 tokens, or (B,60,90) u8 frames (tokenizer fused in front; slots 9..12)"""
         torch = _torch()
-        x = _dev_f32(x)
-        y = torch.empty_like(x)
-        nb = min(x.shape[0], torch.cuda.get_device_properties(x.device).multi_processor_count)
-        st = torch.zeros((nb, 8, 10), dtype=torch.int64, device=x.device)
-        _chk(lib().ita_debug_encoder_stamps(self._h, layer, x.data_ptr(), y.data_ptr(), x.shape[0], st.data_ptr(),
+        B = x.shape[0]
+        if x.dtype == torch.uint8:
+            img, xp = x.reshape(-1, 60, 90).contiguous(), None
+        else:
+            img, xp = None, _dev_f32(x)
+        y = torch.empty((B, 128, self.E), dtype=torch.float32, device=x.device)
+        nb = min(B, torch.cuda.get_device_properties(x.device).multi_processor_count)
+        st = torch.zeros((nb, 8, 16), dtype=torch.int64, device=x.device)
+        _chk(lib().ita_debug_encoder_stamps(self._h, layer, xp.data_ptr() if xp is not None else None,
+                                            img.data_ptr() if img is not None else None, y.data_ptr(), B, st.data_ptr(),
                                             _stream_ptr()))
         return st
 

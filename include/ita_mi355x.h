@@ -151,10 +151,12 @@ int ita_profile_begin_sampled(ita_handle h, int max_forwards, int every_n, int o
 int ita_profile_end(ita_handle h, double* stage_ms, int* n_forwards);
 
 /* Diagnostic: one encoder layer with in-kernel s_memtime stamps (wave 0 of every workgroup, its
- * first 8 frames, 10 phase boundaries): stamps[(block * 8 + frame) * 10 + phase], u64 device buffer
- * of min(batch, #CUs) * 80 entries.  Not used by the product path. */
-int ita_debug_encoder_stamps(ita_handle h, int layer, const float* x_dev, float* y_dev, int batch,
-                             unsigned long long* stamps_dev, void* stream);
+ * first 8 frames, 16 slots): stamps[(block * 8 + frame) * 16 + slot], u64 device buffer of
+ * min(batch, #CUs) * 128 entries.  Slots 0..8: the phase boundaries of the frame; with image_u8_dev
+ * (tokenizer fused in front, x_dev unused) slots 9..12: the steps of tokenizing the NEXT frame.
+ * Not used by the product path. */
+int ita_debug_encoder_stamps(ita_handle h, int layer, const float* x_dev, const void* image_u8_dev, float* y_dev,
+                             int batch, unsigned long long* stamps_dev, void* stream);
 
 /* ---- wire format of the reference's UDP host (ita_wire.h), exported for bindings and tests ------- */
 /* frame_out: [desired_velocity, position_x, quat w, x, y, z]; returns 0, or -1 on a short packet */

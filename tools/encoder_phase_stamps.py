@@ -10,7 +10,8 @@ from drone_oa_iree_vit_accelerator_amd import host, params, synth
 d = params.load_fixture(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "vitlstm_E64_seed0_B2.npz"))
 eng = host.Engine(params.blob_from_record(d, synth.float_params(0), E=64), device=0)
 B = 1024
-x = torch.randn((B, 128, 64), device="cuda")
+fused = len(sys.argv) > 1 and sys.argv[1] == "u8"      # u8 frames: tokenizer fused in front
+x = torch.from_numpy(synth.frames(0, B)["img_u8"]).cuda() if fused else torch.randn((B, 128, 64), device="cuda")
 for _ in range(3):
     st = eng.encoder_stamps(x)
 torch.cuda.synchronize()
@@ -23,5 +24,10 @@ for i, n in enumerate(names):
     print(f"  {n:16s} median {np.median(dt[..., i]):9.0f}  p90 {np.percentile(dt[..., i], 90):9.0f}")
 tot = frames[..., 8] - frames[..., 0]
 print(f"  frame total      median {np.median(tot):9.0f}")
+if fused:
+    tk = frames[..., [8, 9, 10, 11, 12]]
+    for i, n in enumerate(["T0+T1 image/weights -> LDS", "T2 blend", "T3 MFMA", "T4 LayerNorm"]):
+        d = tk[..., i + 1] - tk[..., i]
+        print(f"  tok {n:27s} median {np.median(d):9.0f}  p90 {np.percentile(d, 90):9.0f}")
 whole = st[:, 3, 8] - st[:, 0, 0]
 print(f"  4 frames (wg)    median {np.median(whole):9.0f}; first-frame start spread {st[:, 0, 0].max() - st[:, 0, 0].min()}")
