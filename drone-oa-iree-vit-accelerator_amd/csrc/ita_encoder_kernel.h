@@ -43,7 +43,8 @@ struct ItaEncArgs {
   const int* slots;
   // fused tokenizer (ita_encoder_kernel<true>): u8 wire frames in, tokens never leave the CU
   const uint8_t* img;    // (B,60,90) u8
-  const float* tok_w;    // [53][64]: conv weights k-major (rows 0..48), rows 49..51 zero, row 52 = conv bias
+  const float* tok_w;    // [53][64]: conv weights k-major (rows 0..48), rows 49..51 zero, row 52 = conv bias;
+                         // channel c of an odd row k is stored at c ^ 16 (LDS bank spread for the MFMA B reads)
   const float *tok_lnw, *tok_lnb;
   float* tok_tap;        // optional (B,128,64): the tokens (LayerNorm output of the tokenizer)
 };
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
     lds_barrier();
     ITA_STAMP(9);
     // T2: blended 7x7 patches (conv and bilinear resize are both linear): thread (token, part) takes kernel
-    // rows 2*part, 2*part+1 (part 3: row 6 and the zero pad columns) from a 4 x 9 pixel window
+    // rows 2*part, 2*part+1 (part 3: row 6 and the zero pad columns)
     {
       const int part = qtr, tl = token & 15;
       int y0, yp, x0, xp;
@@ -283,25 +284,25 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
       bilinear_src_dev(token >> 4, 30.0f / 8.0f, 30, y0, yp, ly);
       bilinear_src_dev(token & 15, 45.0f / 16.0f, 45, x0, xp, lx);
       const float h1 = ly, h0 = 1.0f - ly, w1 = lx, w0 = 1.0f - lx;
-      const float* win = img + (2 * y0 + 2 * part) * 96 + 2 * x0;   // (-3 conv padding) + (3 border) = 0; 8-byte aligned
-      float f[4][10];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int c = 0; c < 5; ++c) {
-          const f32x2 two = *(const f32x2*)(win + j * 96 + 2 * c);
-          f[j][2 * c] = two.x;
-          f[j][2 * c + 1] = two.y;
-        }
+      // the four bilinear neighbours of a tap are the same window shifted by (2*yp rows, 2*xp columns): four
+      // 8-byte aligned row reads instead of selects; two taps per VALU op (v_pk_mul_f32 / v_pk_add_f32 round
+      // exactly like the scalar ops)
+      const float* wa = img + (2 * y0 + 2 * part) * 96 + 2 * x0;   // (-3 conv padding) + (3 border) = 0
+      const float* wb = wa + 2 * xp;
+      const float* wc = wa + 2 * yp * 96;
+      const float* wd = wc + 2 * xp;
+      const f32x2 h0v = {h0, h0}, h1v = {h1, h1}, w0v = {w0, w0}, w1v = {w1, w1};
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
         if (jj == 0 || part < 3) {
+          float* prow = pb + tl * 52 + (2 * part + jj) * 7;
 #pragma unroll
-          for (int kx = 0; kx < 7; ++kx) {
-            const float va = f[jj][kx], vb = xp ? f[jj][kx + 2] : va;
-            const float vc = yp ? f[jj + 2][kx] : va;
-            const float vd = yp ? (xp ? f[jj + 2][kx + 2] : f[jj + 2][kx]) : vb;
-            pb[tl * 52 + (2 * part + jj) * 7 + kx] = h0 * (w0 * va + w1 * vb) + h1 * (w0 * vc + w1 * vd);
+          for (int c = 0; c < 4; ++c) {
+            const f32x2 va = *(const f32x2*)(wa + jj * 96 + 2 * c), vb = *(const f32x2*)(wb + jj * 96 + 2 * c);
+            const f32x2 vc = *(const f32x2*)(wc + jj * 96 + 2 * c), vd = *(const f32x2*)(wd + jj * 96 + 2 * c);
+            const f32x2 t = h0v * (w0v * va + w1v * vb) + h1v * (w0v * vc + w1v * vd);
+            prow[2 * c] = t.x;
+            if (c < 3) prow[2 * c + 1] = t.y;
           }
         }
       }
@@ -325,7 +326,8 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
         const float av = pb[col * 52 + 4 * s + kq];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
-          acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wt[(4 * s + kq) * 64 + ct * 16 + col], acc[ct], 0, 0, 0);
+          acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wt[(4 * s + kq) * 64 + ((ct * 16 + col) ^ ((kq & 1) << 4))],
+                                                         acc[ct], 0, 0, 0);
       }
       __builtin_amdgcn_wave_barrier();
       // C layout: col = channel ct*16 + (lane&15), row = token 4*(lane>>4) + i  -> pre[token][68] over the patches

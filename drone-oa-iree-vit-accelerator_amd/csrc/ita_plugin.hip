@@ -67,7 +67,8 @@ struct ita_context {
   // derived device buffers
   float* tail_wT = nullptr;
   float* tok_wT = nullptr;                 // [50][E] conv7x7 weights k-major, row 49 = 0
-  float* tok_w16 = nullptr;                // [53][64] for the tokenizer fused into the encoder: rows 49..51 = 0, row 52 = conv bias
+  float* tok_w16 = nullptr;                // [53][64] for the tokenizer fused into the encoder: rows 49..51 = 0, row 52 = conv
+                                           // bias; channel c of odd row k sits at c ^ 16
   float* wcat[3] = {nullptr, nullptr, nullptr};
   float* bsum[3] = {nullptr, nullptr, nullptr};
   // split-precision (f16 hi/lo) tail: folded tail+decoder matrix and LSTM weights, pre-scaled
@@ -559,8 +560,11 @@ int ita_load_weights(ita_handle h, const void* blob, size_t nbytes) {
     HIPCHK(hipMemcpy(h->tok_wT, wT.data(), wT.size() * sizeof(float), hipMemcpyHostToDevice));
     const float* cb = hptr<float>(h, "tok.conv_b");
     if (Ei == 64 && cb) {
+      // rows are read by the MFMA four at a time (k = 4s .. 4s+3 in the four 16-lane groups): odd rows
+      // are stored with the two 16-channel halves of each 32 swapped so the groups hit disjoint LDS banks
       std::vector<float> w16((size_t)53 * 64, 0.0f);
-      memcpy(w16.data(), wT.data(), sizeof(float) * 49 * 64);
+      for (int k = 0; k < 49; ++k)
+        for (int c = 0; c < 64; ++c) w16[(size_t)k * 64 + (c ^ ((k & 1) << 4))] = wT[(size_t)k * Ei + c];
       memcpy(&w16[(size_t)52 * 64], cb, sizeof(float) * 64);
       HIPCHK(hipMalloc(&h->tok_w16, w16.size() * sizeof(float)));
       HIPCHK(hipMemcpy(h->tok_w16, w16.data(), w16.size() * sizeof(float), hipMemcpyHostToDevice));
