@@ -45,7 +45,7 @@ STAGE_WORK = {   # stage: (ops per frame, bound, peak in Tera-op/s, arithmetic)
 # dominant-stage -> kernel whose PMC traffic (profiles/kernel_traffic.json, collected with
 # tools/profile_gpu.sh on this same command) is reported as roofline.traffic
 STAGE_KERNEL = {"encoder": "ita_encoder_kernel<true>", "tokenizer": "ita_tokenizer_kernel<64, false>",
-                "tail_decoder": "ita_gemm_f16x3_kernel<128, 128, 2, 4, false>", "lstm_fc": "ita_lstm_layer_kernel<11>"}
+                "tail_decoder": "ita_gemm_f16x3_kernel<128, 128, 2, 4>", "lstm_fc": "ita_lstm_layer_kernel<4>"}
 # algorithmic HBM bytes per frame of each stage as it is cut here (inputs + outputs that cross a launch)
 STAGE_BYTES = {"tokenizer": 21600 + 128 * 64 * 4, "encoder": 128 * 64 * 4 + 2 * 128 * 64 * 2,
                "tail_decoder": 2 * 128 * 64 * 2 + 512 * 4, "lstm_fc": 2 * 3 * 128 * 4 * 2 + 12}

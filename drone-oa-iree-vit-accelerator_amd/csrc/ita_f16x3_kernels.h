@@ -61,23 +61,6 @@ __device__ __forceinline__ void stage_plane(const _Float16* __restrict__ g, int 
   }
 }
 
-// register-staged alternative: the same LDS image, filled by global_load_dwordx4 -> ds_write_b128
-template <int ROWS, int NT>
-__device__ __forceinline__ void fetch_plane(const _Float16* __restrict__ g, int ld, int row0, int max_row, int k0,
-                                            i32x4 (&v)[ROWS * 8 / NT], int tid) {
-#pragma unroll
-  for (int p = 0; p < ROWS * 8 / NT; ++p) {
-    const int piece = p * NT + tid, r = piece >> 3, s = piece & 7;
-    const int c = s ^ ((r >> 1) & 7);
-    v[p] = *(const i32x4*)(g + (size_t)min(row0 + r, max_row) * ld + k0 + c * 8);
-  }
-}
-template <int ROWS, int NT>
-__device__ __forceinline__ void put_plane(char* lds_plane, const i32x4 (&v)[ROWS * 8 / NT], int tid) {
-#pragma unroll
-  for (int p = 0; p < ROWS * 8 / NT; ++p) *(i32x4*)(lds_plane + (p * NT + tid) * 16) = v[p];
-}
-
 __device__ __forceinline__ f16x8 frag_f16(const char* lds_plane, int r, int chunk) {
   return *(const f16x8*)(lds_plane + r * 128 + ((chunk ^ ((r >> 1) & 7)) << 4));
 }
@@ -91,7 +74,7 @@ struct ItaGemmSplitLds {
 
 // WM x WN waves; each wave owns a (BM/WM) x (BN/WN) block of 32x32 MFMA tiles.  Two waves per SIMD
 // (WM*WN = 8) let one wave's MFMAs run while its partner waits for the LDS-DMA of the next K tile.
-template <int BM, int BN, int WM, int WN, bool REG = false>
+template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN) void ita_gemm_f16x3_kernel(const ItaGemmSplitArgs g) {
   using L = ItaGemmSplitLds<BM, BN>;
   constexpr int NT = 64 * WM * WN;
@@ -156,41 +139,13 @@ __global__ __launch_bounds__(64 * WM * WN) void ita_gemm_f16x3_kernel(const ItaG
     }
   };
   int cur = 0;
-  if constexpr (!REG) {
-    stage(0, 0);
-    __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
-    for (int t = 0; t < nt; ++t) {
-      if (t + 1 < nt && !(g.dbg & 2)) stage(cur ^ 1, t + 1);
-      if (!(g.dbg & 1)) compute(g.dbg & 8 ? 0 : cur);
-      if (!(g.dbg & 4)) __syncthreads();
-      cur ^= 1;
-    }
-  } else {
-    i32x4 rah[BM * 8 / NT], ral[BM * 8 / NT], rwh[BN * 8 / NT], rwl[BN * 8 / NT];
-    auto fetch = [&](int t) {
-      const int k0 = kbeg + t * 64;
-      fetch_plane<BM, NT>(g.a_hi, g.lda, m0, g.M - 1, k0, rah, tid);
-      fetch_plane<BM, NT>(g.a_lo, g.lda, m0, g.M - 1, k0, ral, tid);
-      fetch_plane<BN, NT>(g.w_hi, g.ldw, n0, g.N - 1, k0, rwh, tid);
-      fetch_plane<BN, NT>(g.w_lo, g.ldw, n0, g.N - 1, k0, rwl, tid);
-    };
-    auto put = [&](int buf) {
-      char* b = lds + buf * L::BUF;
-      put_plane<BM, NT>(b, rah, tid);
-      put_plane<BM, NT>(b + L::A_PLANE, ral, tid);
-      put_plane<BN, NT>(b + 2 * L::A_PLANE, rwh, tid);
-      put_plane<BN, NT>(b + 2 * L::A_PLANE + L::W_PLANE, rwl, tid);
-    };
-    fetch(0);
-    put(0);
-    __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-      if (t + 1 < nt) fetch(t + 1);          // loads in flight during the MFMAs of tile t
-      compute(cur);
-      if (t + 1 < nt) put(cur ^ 1);          // buffer cur^1 was last read in iteration t-1 (barrier below)
-      __syncthreads();
-      cur ^= 1;
-    }
+  stage(0, 0);
+  __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt && !(g.dbg & 2)) stage(cur ^ 1, t + 1);
+    if (!(g.dbg & 1)) compute(g.dbg & 8 ? 0 : cur);
+    if (!(g.dbg & 4)) __syncthreads();
+    cur ^= 1;
   }
   // C layout: col n = lane&31, row m = (e&3) + 8*(e>>2) + 4*h
   float* out = g.out + (size_t)zsplit * g.M * g.N;

@@ -321,14 +321,14 @@ int launch_gemm(const float* A, int lda, const float* W, int ldw, const float* b
   return ITA_OK;
 }
 
-template <int BM, int BN, int WM, int WN, bool REG = false>
+template <int BM, int BN, int WM, int WN>
 int launch_gemm_split(const _Float16* a_hi, const _Float16* a_lo, int lda, const _Float16* w_hi, const _Float16* w_lo,
                       int ldw, float* out, int M, int N, int K, int nsplit, hipStream_t s) {
   if (N % BN || K % (64 * nsplit)) return fail(ITA_ERR_UNSUPPORTED, "split gemm shape");
   static const int dbg = getenv("ITA_GEMM_DBG") ? atoi(getenv("ITA_GEMM_DBG")) : 0;
   ItaGemmSplitArgs g{a_hi, a_lo, lda, w_hi, w_lo, ldw, out, M, N, K, nsplit, dbg};
   constexpr int lds_bytes = ItaGemmSplitLds<BM, BN>::TOTAL;
-  auto kern = ita_gemm_f16x3_kernel<BM, BN, WM, WN, REG>;
+  auto kern = ita_gemm_f16x3_kernel<BM, BN, WM, WN>;
   hipLaunchKernelGGL(kern, dim3((N / BN) * ((M + BM - 1) / BM) * nsplit), dim3(64 * WM * WN), lds_bytes, s, g);
   HIPCHK(hipGetLastError());
   return ITA_OK;
@@ -466,8 +466,6 @@ int ita_create(ita_handle* out, int device_ordinal) {
   if ((rc = set_lds(ita_encoder_kernel<true>, ItaEncLds::TOTAL))) { delete c; return rc; }
   {
     auto k1 = ita_gemm_f16x3_kernel<128, 128, 2, 4>;
-    auto k1r = ita_gemm_f16x3_kernel<128, 128, 2, 4, true>;
-    if ((rc = set_lds(k1r, ItaGemmSplitLds<128, 128>::TOTAL))) { delete c; return rc; }
     constexpr int b1 = ItaGemmSplitLds<128, 128>::TOTAL;
     if ((rc = set_lds(k1, b1))) { delete c; return rc; }
   }
@@ -760,12 +758,8 @@ static int forward_impl(ita_handle h, const void* image, int image_dtype, const 
   if (taps && taps->x2) HIPCHK(hipMemcpyAsync(taps->x2, h->bufA, tokb, hipMemcpyDeviceToDevice, s));
   if (fast) {
     // folded tail+decoder: dec = x2 . Wfold^T + bias'   (x2 planes were written by the last FFN)
-    static const bool reg_stage = getenv("ITA_GEMM_REG") != nullptr;
-    if (reg_stage) {
-      if ((rc = launch_gemm_split<128, 128, 2, 4, true>(h->x2_hi, h->x2_lo, LDFOLD, h->fold_hi, h->fold_lo, LDFOLD, h->part,
-                                                        B, 512, KFOLD, NSPLIT, s))) return rc;
-    } else if ((rc = launch_gemm_split<128, 128, 2, 4>(h->x2_hi, h->x2_lo, LDFOLD, h->fold_hi, h->fold_lo, LDFOLD, h->part, B,
-                                                       512, KFOLD, NSPLIT, s))) return rc;
+    if ((rc = launch_gemm_split<128, 128, 2, 4>(h->x2_hi, h->x2_lo, LDFOLD, h->fold_hi, h->fold_lo, LDFOLD, h->part, B,
+                                                512, KFOLD, NSPLIT, s))) return rc;
     MARK();
     MARK();
     _Float16* chi[3] = {nullptr, h->c1_hi, h->c2_hi};

@@ -18,8 +18,9 @@ rows.sort()
 short = lambda n: n.split("(")[0].split("<")[0].replace("void ", "")[:28]
 # a step starts at every tokenizer launch
 steps, cur = [], None
+first = "tokenizer" if any("tokenizer" in n for _, _, n in rows) else "ita_encoder_kernel"   # first kernel of a step
 for s, e, n in rows:
-    if "tokenizer" in n:
+    if first in n:
         cur = []
         steps.append(cur)
     if cur is not None:
