@@ -370,3 +370,147 @@ __global__ void ita_impulse_kernel(float* x, int rows, int width, int col0) {
   const int i = (int)(idx / width), c = (int)(idx % width);
   x[idx] = (c == col0 + i) ? 1.0f : 0.0f;
 }
+
+// ------------------------------------------------------------------ fusion tail on large token grids
+// BASELINE config 5: the layers of QAT/model.py:116-121 on a tok_h x tok_w
+// token grid with out_ch conv outputs,  x (B, tok_h*tok_w, E) f32 -> out (B, out_ch, 2 tok_h, 2 tok_w) f32:
+// PixelShuffle(2) || Upsample(x2, bilinear, align_corners=True) -> cat (5E/4 channels) -> conv3x3 pad 1.
+// At 64 x 128 tokens, E = 128, 48 outputs this is 2.26 G MAC per frame against 5 MB of traffic: an
+// implicit GEMM on split-precision f16 MFMA (hi + lo operand planes, three products, f32 accumulate --
+// the same scheme and error, ~2^-22 relative, as ita_gemm_f16x3_kernel), never materialising the
+// 160-channel concatenated map:
+//   workgroup = 4 waves = one 8 x 32 output tile, all output channels; wave w owns rows 2w, 2w+1 as four
+//   16-pixel M tiles x NT 16-channel N tiles of v_mfma_f32_16x16x32_f16;
+//   K loop: channel chunks of 32 x 9 taps; per chunk the 10 x 34 halo of the concatenated map is BUILT in
+//   LDS from the tokens (shuffle gather / exact f32 bilinear blend, then split into f16 hi + lo,
+//   pixel-major [pixel][32 ch]) next to the chunk's weights [tap][co][32 ch] (prepared at load time).
+struct ItaTailBigArgs {
+  const float* x;                 // (B, TH*TW, E)
+  const _Float16 *w_hi, *w_lo;    // [chunks][9 taps][NT*16][32] pre-scaled, zero padded
+  const float* bias;              // [NT*16]
+  float inv_wscale;
+  float* out;                     // (B, CO, 2TH, 2TW)
+  int B, E, TH, TW, CO, nchunk;
+};
+template <int NT>
+struct ItaTailBigLds {
+  static constexpr int HP = 10 * 34;                       // halo pixels of an 8 x 32 tile
+  static constexpr int A_PLANE = HP * 64;                  // [pixel][32 ch] f16
+  static constexpr int W_PLANE = 9 * NT * 16 * 64;         // [tap][co][32 ch] f16
+  static constexpr int AH = 0, AL = A_PLANE, WH = 2 * A_PLANE, WL = WH + W_PLANE;
+  static constexpr int TOTAL = WL + W_PLANE;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void ita_tail_big_kernel(const ItaTailBigArgs a) {
+  using L = ItaTailBigLds<NT>;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int OH = 2 * a.TH, OW = 2 * a.TW, C4 = a.E / 4, CIN = C4 + a.E;
+  const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 8, b = blockIdx.z;
+  const float* xt = a.x + (size_t)b * a.TH * a.TW * a.E;
+  const float sy = (float)(a.TH - 1) / (float)(OH - 1), sx = (float)(a.TW - 1) / (float)(OW - 1);
+
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+
+  for (int ch = 0; ch < a.nchunk; ++ch) {
+    __syncthreads();   // the previous chunk's fragments are consumed
+    // ---- weights of this chunk: a straight 16-byte copy (already in fragment order)
+    {
+      const i32x4* gh = (const i32x4*)(a.w_hi + (size_t)ch * (L::W_PLANE / 2));
+      const i32x4* gl = (const i32x4*)(a.w_lo + (size_t)ch * (L::W_PLANE / 2));
+      for (int i = tid; i < L::W_PLANE / 16; i += 256) {
+        *(i32x4*)(lds + L::WH + 16 * i) = gh[i];
+        *(i32x4*)(lds + L::WL + 16 * i) = gl[i];
+      }
+    }
+    // ---- halo of the concatenated map, channels 32ch .. 32ch+31: thread = (pixel, 4 channels)
+    for (int i = tid; i < L::HP * 8; i += 256) {
+      const int p = i >> 3, cq = i & 7;
+      const int hy = p / 34, hx = p - 34 * hy;
+      const int y = ty0 + hy - 1, x = tx0 + hx - 1;
+      const int c0 = ch * 32 + 4 * cq;
+      float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (y >= 0 && y < OH && x >= 0 && x < OW && c0 < CIN) {
+        if (c0 < C4) {   // PixelShuffle(2): out[c][2h+i][2w+j] = in[4c+2i+j][h][w]
+          const float* t = xt + (size_t)((y >> 1) * a.TW + (x >> 1)) * a.E + 2 * (y & 1) + (x & 1);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = (c0 + j < C4) ? t[4 * (c0 + j)] : 0.0f;
+        }
+        if (c0 + 3 >= C4) {   // bilinear x2, align_corners=True (ita_tail_kernel's / the oracle's expression)
+          const float fy = sy * (float)y, fx = sx * (float)x;
+          int y0 = (int)fy, x0 = (int)fx;
+          if (y0 > a.TH - 1) y0 = a.TH - 1;
+          if (x0 > a.TW - 1) x0 = a.TW - 1;
+          const int yp = y0 < a.TH - 1 ? 1 : 0, xp = x0 < a.TW - 1 ? 1 : 0;
+          const float h1 = fy - (float)y0, h0 = 1.0f - h1, w1 = fx - (float)x0, w0 = 1.0f - w1;
+          const float* t00 = xt + (size_t)(y0 * a.TW + x0) * a.E;
+          const float* t01 = t00 + (size_t)xp * a.E;
+          const float* t10 = t00 + (size_t)yp * a.TW * a.E;
+          const float* t11 = t10 + (size_t)xp * a.E;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int c = c0 + j - C4;
+            if (c >= 0 && c < a.E) v[j] = h0 * (w0 * t00[c] + w1 * t01[c]) + h1 * (w0 * t10[c] + w1 * t11[c]);
+          }
+        }
+      }
+      f16x4 vh, vl;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        _Float16 q, r;
+        split_f16(v[j], q, r);
+        vh[j] = q; vl[j] = r;
+      }
+      *(f16x4*)(lds + L::AH + p * 64 + cq * 8) = vh;
+      *(f16x4*)(lds + L::AL + p * 64 + cq * 8) = vl;
+    }
+    __syncthreads();
+    // ---- 9 taps x (4 M tiles x NT N tiles) x 3 products; A lane = (pixel l&15, channels 8(l>>4)..+7)
+    const int px = lane & 15, kg = lane >> 4;
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      f16x8 bh[NT], bl[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int off = ((tap * NT * 16 + nt * 16 + px) * 64) + kg * 16;
+        bh[nt] = *(const f16x8*)(lds + L::WH + off);
+        bl[nt] = *(const f16x8*)(lds + L::WL + off);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int hp = (2 * wave + (mt >> 1) + ky) * 34 + (mt & 1) * 16 + px + kx;
+        const f16x8 ah = *(const f16x8*)(lds + L::AH + hp * 64 + kg * 16);
+        const f16x8 al = *(const f16x8*)(lds + L::AL + hp * 64 + kg * 16);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[nt], acc[mt][nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // C layout: column n = lane&15 (output channel), rows m = 4*(lane>>4) + i (pixel)
+  const int co_l = lane & 15, m0 = 4 * (lane >> 4);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int y = ty0 + 2 * wave + (mt >> 1), x = tx0 + (mt & 1) * 16 + m0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int co = nt * 16 + co_l;
+      if (co < a.CO) {
+        const float bv = a.bias[co];
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = acc[mt][nt][i] * a.inv_wscale + bv;
+        *(f32x4*)(a.out + (((size_t)b * a.CO + co) * OH + y) * OW + x) = o;
+      }
+    }
+  }
+}

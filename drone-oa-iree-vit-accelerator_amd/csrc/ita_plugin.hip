@@ -92,6 +92,11 @@ struct ita_context {
   int prof_max = 0, prof_n = 0;
   int prof_every = 1, prof_stage = -1, prof_calls = 0;   // sample every n-th forward; -1 = all stages, else one stage
   std::vector<hipEvent_t> prof_ev;   // per recorded forward: 1 + 1 + 2*L + 3 events
+  // fusion tail on large token grids (ita_fusion_tail_load / _large, BASELINE config 5)
+  _Float16 *tl_hi = nullptr, *tl_lo = nullptr;   // [chunks][9][nt*16][32]
+  float* tl_bias = nullptr;
+  float tl_inv_scale = 1.0f;
+  int tl_E = 0, tl_CO = 0, tl_nt = 0, tl_nchunk = 0;
   // staging for the host-buffer drop-in symbols
   float *dsp_in = nullptr, *dsp_out = nullptr;
   std::vector<float> dsp_host;
@@ -321,6 +326,19 @@ int launch_gemm(const float* A, int lda, const float* W, int ldw, const float* b
   return ITA_OK;
 }
 
+template <int NT>
+int launch_tail_big(ita_context* c, const ItaTailBigArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(ita_tail_big_kernel<NT>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, ItaTailBigLds<NT>::TOTAL));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(ita_tail_big_kernel<NT>, dim3(2 * a.TW / 32, 2 * a.TH / 8, a.B), dim3(256), ItaTailBigLds<NT>::TOTAL, s, a);
+  HIPCHK(hipGetLastError());
+  return ITA_OK;
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_gemm_split(const _Float16* a_hi, const _Float16* a_lo, int lda, const _Float16* w_hi, const _Float16* w_lo,
                       int ldw, float* out, int M, int N, int K, int nsplit, hipStream_t s) {
@@ -473,6 +491,8 @@ int ita_create(ita_handle* out, int device_ordinal) {
   return ITA_OK;
 }
 
+static void free_tail_large(ita_context* c);
+
 int ita_destroy(ita_handle h) {
   if (!h) return fail(ITA_ERR_INVALID_ARG, "null handle");
   {
@@ -485,6 +505,7 @@ int ita_destroy(ita_handle h) {
   for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
   if (h->dsp_in) (void)hipFree(h->dsp_in);
   if (h->dsp_out) (void)hipFree(h->dsp_out);
+  free_tail_large(h);
   delete h;
   return ITA_OK;
 }
@@ -694,6 +715,67 @@ int ita_fusion_tail(ita_handle h, const float* x, float* feat, int batch, void* 
   if (rc) return rc;
   if (!x || !feat) return fail(ITA_ERR_INVALID_ARG, "null pointer");
   return launch_tail(h, x, feat, 4608, batch, (hipStream_t)stream);
+}
+
+static void free_tail_large(ita_context* c) {
+  if (c->tl_hi) (void)hipFree(c->tl_hi);
+  if (c->tl_lo) (void)hipFree(c->tl_lo);
+  if (c->tl_bias) (void)hipFree(c->tl_bias);
+  c->tl_hi = c->tl_lo = nullptr;
+  c->tl_bias = nullptr;
+  c->tl_E = c->tl_CO = c->tl_nt = c->tl_nchunk = 0;
+}
+
+int ita_fusion_tail_load(ita_handle h, const float* conv_w, const float* conv_b, int E, int out_ch) {
+  int rc = check(h, 1, false);
+  if (rc) return rc;
+  if (!conv_w || !conv_b) return fail(ITA_ERR_INVALID_ARG, "null pointer");
+  if (E <= 0 || E % 16 || out_ch <= 0 || out_ch > 64) return fail(ITA_ERR_UNSUPPORTED, "needs E % 16 == 0 and out_ch <= 64");
+  free_tail_large(h);
+  const int CIN = E / 4 + E, nchunk = (CIN + 31) / 32, nt = (out_ch + 15) / 16, cop = nt * 16;
+  // same scaling rule as split_upload: max |w| * 2^e in [512, 1024) keeps the lo halves normal in f16
+  float mx = 0.0f;
+  for (size_t i = 0; i < (size_t)out_ch * CIN * 9; ++i) mx = fabsf(conv_w[i]) > mx ? fabsf(conv_w[i]) : mx;
+  int e = 0;
+  if (mx > 0.0f) { int ex; frexpf(mx, &ex); e = 10 - ex; }
+  const float sc = ldexpf(1.0f, e);
+  std::vector<uint16_t> hi((size_t)nchunk * 9 * cop * 32, 0), lo(hi.size(), 0);
+  for (int co = 0; co < out_ch; ++co)
+    for (int c = 0; c < CIN; ++c)
+      for (int tap = 0; tap < 9; ++tap) {
+        const float v = conv_w[((size_t)co * CIN + c) * 9 + tap] * sc;
+        const size_t d = (((size_t)(c / 32) * 9 + tap) * cop + co) * 32 + (c % 32);
+        hi[d] = float_to_half(v);
+        lo[d] = float_to_half(v - half_to_float(hi[d]));
+      }
+  std::vector<float> bias(cop, 0.0f);
+  memcpy(bias.data(), conv_b, sizeof(float) * out_ch);
+  HIPCHK(hipMalloc(&h->tl_hi, hi.size() * 2));
+  HIPCHK(hipMalloc(&h->tl_lo, lo.size() * 2));
+  HIPCHK(hipMalloc(&h->tl_bias, bias.size() * sizeof(float)));
+  HIPCHK(hipMemcpy(h->tl_hi, hi.data(), hi.size() * 2, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->tl_lo, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->tl_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+  h->tl_inv_scale = ldexpf(1.0f, -e);
+  h->tl_E = E; h->tl_CO = out_ch; h->tl_nt = nt; h->tl_nchunk = nchunk;
+  return ITA_OK;
+}
+
+int ita_fusion_tail_large(ita_handle h, const float* x, float* out, int batch, int tok_h, int tok_w, void* stream) {
+  int rc = check(h, batch, false);
+  if (rc) return rc;
+  if (!x || !out) return fail(ITA_ERR_INVALID_ARG, "null pointer");
+  if (!h->tl_hi) return fail(ITA_ERR_NO_WEIGHTS, "ita_fusion_tail_load has not been called");
+  if (tok_h < 4 || tok_w < 16 || (2 * tok_h) % 8 || (2 * tok_w) % 32 || batch > 65535)
+    return fail(ITA_ERR_UNSUPPORTED, "needs tok_h % 4 == 0, tok_w % 16 == 0, batch <= 65535");
+  ItaTailBigArgs a{x, h->tl_hi, h->tl_lo, h->tl_bias, h->tl_inv_scale, out, batch, h->tl_E, tok_h, tok_w, h->tl_CO, h->tl_nchunk};
+  hipStream_t s = (hipStream_t)stream;
+  switch (h->tl_nt) {
+    case 1: return launch_tail_big<1>(h, a, s);
+    case 2: return launch_tail_big<2>(h, a, s);
+    case 3: return launch_tail_big<3>(h, a, s);
+    default: return launch_tail_big<4>(h, a, s);
+  }
 }
 
 static int forward_impl(ita_handle h, const void* image, int image_dtype, const float* desvel, const float* quat,

@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = (
     "ita_last_error", "ita_error_string", "ita_mha_int8", "ita_mha_int8_taps", "ita_ffn_int8", "ita_ffn_int8_taps",
     "ita_encoder_layer", "ita_tokenizer", "ita_fusion_tail", "ita_vitlstm_forward", "ita_bind_dispatch",
     "ita_profile_begin", "ita_profile_begin_sampled", "ita_profile_end", "ita_set_tail_mode", "ita_debug_encoder_stamps",
+    "ita_fusion_tail_load", "ita_fusion_tail_large",
     "ita_wire_unpack_packet", "ita_wire_postprocess", "ita_vitlstm_forward_slots", "ita_vitlstm_front",
     "ita_vitlstm_back",
     "ITASelfAttention_workgroup", "ITASelfAttention_workgroup_expanded", "ITAFeedForward_workgroup",
@@ -120,6 +121,8 @@ def lib():
         L.ita_wire_postprocess.restype = None
         L.ita_set_tail_mode.argtypes = [vp, i]
         L.ita_debug_encoder_stamps.argtypes = [vp, i, vp, vp, vp, i, vp, vp]
+        L.ita_fusion_tail_load.argtypes = [vp, vp, vp, i, i]
+        L.ita_fusion_tail_large.argtypes = [vp, vp, vp, i, i, i, vp]
         L.ita_profile_begin.argtypes = [vp, i]
         L.ita_profile_begin_sampled.argtypes = [vp, i, i, i]
         L.ita_profile_end.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i)]
@@ -358,6 +361,51 @@ class Engine:
     # ---- drop-in symbols (host buffers) --------------------------------------------------
     def bind_dispatch(self, layer: int = 0, dtype: int = DISPATCH_F16):
         _chk(lib().ita_bind_dispatch(self._h, layer, dtype))
+
+
+class FusionTailLarge:
+    """The fusion tail (PixelShuffle(2) || Upsample x2 align_corners -> cat -> Conv2d 3x3) on an arbitrary
+    token grid -- BASELINE config 5 (reference models/ITA_single_layer_upsample_shuffle/QAT/model.py:116-121,
+    layer sizes of models/ITA_upsample_shuffle/model.py:70-79).  conv_w (CO, 5E/4, 3, 3), conv_b (CO,): numpy."""
+
+    def __init__(self, conv_w, conv_b, device: Optional[int] = None):
+        import numpy as np
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise ITAError("no GPU visible: the ITA engine has no CPU path")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        w = np.ascontiguousarray(conv_w, dtype=np.float32)
+        b = np.ascontiguousarray(conv_b, dtype=np.float32)
+        self.CO, cin = w.shape[0], w.shape[1]
+        self.E = cin * 4 // 5
+        if w.shape[2:] != (3, 3) or self.E // 4 + self.E != cin or b.shape != (self.CO,):
+            raise ITAError("conv_w must be (CO, 5E/4, 3, 3) and conv_b (CO,)")
+        self._h = C.c_void_p()
+        _chk(lib().ita_create(C.byref(self._h), self.device))
+        _chk(lib().ita_fusion_tail_load(self._h, w.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), self.E, self.CO))
+
+    def __call__(self, x, tok_h: int, tok_w: int, out=None):
+        """x (B, tok_h*tok_w, E) f32 on the GPU -> (B, CO, 2 tok_h, 2 tok_w) f32"""
+        torch = _torch()
+        x = _dev_f32(x)
+        B = x.shape[0]
+        if x.shape[1] != tok_h * tok_w or x.shape[2] != self.E:
+            raise ITAError(f"x must be (B, {tok_h * tok_w}, {self.E})")
+        if out is None:
+            out = torch.empty((B, self.CO, 2 * tok_h, 2 * tok_w), dtype=torch.float32, device=x.device)
+        _chk(lib().ita_fusion_tail_large(self._h, x.data_ptr(), out.data_ptr(), B, tok_h, tok_w, _stream_ptr()))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().ita_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class ITAViTLSTM:

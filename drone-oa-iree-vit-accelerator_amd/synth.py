@@ -79,6 +79,17 @@ def frames(seed: int, B: int, gain: float = 1.0) -> dict:
     return dict(img_u8=img, desvel=desvel, quat=quat)
 
 
+def tail_large_case(seed: int, E: int, tok_h: int, tok_w: int, out_ch: int, B: int) -> dict:
+    """Seeded inputs of the large-grid fusion tail (BASELINE config 5): tokens, conv weight (out_ch, 5E/4, 3, 3)
+    with the fan-in scaling of nn.Conv2d's default init, bias.  numpy legacy RandomState: stable across versions."""
+    rs = np.random.RandomState(4321 + seed)
+    cin = E // 4 + E
+    bound = 1.0 / np.sqrt(cin * 9)
+    return dict(x=rs.standard_normal((B, tok_h * tok_w, E)).astype(np.float32),
+                conv_w=rs.uniform(-bound, bound, size=(out_ch, cin, 3, 3)).astype(np.float32),
+                conv_b=rs.uniform(-bound, bound, size=(out_ch,)).astype(np.float32))
+
+
 def digest(params: dict) -> str:
     """sha256 over the float params in key order: committed with each fixture so a
     drift of the generator is detected instead of silently changing the expected outputs."""

@@ -150,6 +150,18 @@ int ita_profile_begin(ita_handle h, int max_forwards);
 int ita_profile_begin_sampled(ita_handle h, int max_forwards, int every_n, int only_stage);
 int ita_profile_end(ita_handle h, double* stage_ms, int* n_forwards);
 
+/* ---- fusion tail on large token grids (BASELINE config 5) ----------------
+ * The layers of models/ITA_single_layer_upsample_shuffle/QAT/model.py:116-121 -- PixelShuffle(2) ||
+ * Upsample(x2, bilinear, align_corners=True) -> cat -> Conv2d(5E/4 -> out_ch, 3, padding 1) -- on a
+ * tok_h x tok_w token grid (models/ITA_upsample_shuffle/model.py:70-79 declares them with E = 128 and
+ * 48 outputs):  x_dev (B, tok_h*tok_w, E) f32 -> out_dev (B, out_ch, 2 tok_h, 2 tok_w) f32.
+ * ita_fusion_tail_load takes HOST pointers (conv weight (out_ch, 5E/4, 3, 3), bias (out_ch)), once;
+ * it is independent of ita_load_weights.  Split-precision f16 MFMA, result within 1e-5 relative of
+ * the f32 oracle.  Needs E % 16 == 0, out_ch <= 64, tok_h % 4 == 0, tok_w % 16 == 0. */
+int ita_fusion_tail_load(ita_handle h, const float* conv_w_host, const float* conv_b_host, int E, int out_ch);
+int ita_fusion_tail_large(ita_handle h, const float* x_dev, float* out_dev, int batch, int tok_h, int tok_w,
+                          void* stream);
+
 /* Diagnostic: one encoder layer with in-kernel s_memtime stamps (wave 0 of every workgroup, its
  * first 8 frames, 16 slots): stamps[(block * 8 + frame) * 16 + slot], u64 device buffer of
  * min(batch, #CUs) * 128 entries.  Slots 0..8: the phase boundaries of the frame; with image_u8_dev

@@ -316,34 +316,33 @@ static void upsample_src_ac(int dst, int in, int out, int* i0, int* ip, float* l
   *l1 = src - (float)i;
 }
 
-void ita_oracle_tail(const float* x2, int B, int E, const float* cw, const float* cb, float* feat,
-                     float* t_fused /* optional (B, 5E/4, 16, 32) */) {
-  const int C4 = E / 4, CIN = C4 + E, OH = 16, OW = 32;
+/* General form (BASELINE config 5): the same three layers on a tok_h x tok_w token
+ * grid with out_ch conv outputs: x2 (B, tok_h*tok_w, E) -> out (B, out_ch, 2*tok_h, 2*tok_w). */
+static float tail_fused_at(const float* xt, int E, int TH, int TW, int c, int y, int x) {
+  const int C4 = E / 4, OH = 2 * TH, OW = 2 * TW;
+  if (y < 0 || y >= OH || x < 0 || x >= OW) return 0.0f;
+  if (c < C4) return xt[(size_t)((y >> 1) * TW + (x >> 1)) * E + (4 * c + 2 * (y & 1) + (x & 1))];
+  c -= C4;
+  int y0, yp, x0, xp; float ly, lx;
+  upsample_src_ac(y, TH, OH, &y0, &yp, &ly);
+  upsample_src_ac(x, TW, OW, &x0, &xp, &lx);
+  const float h1 = ly, h0 = 1.0f - ly, w1 = lx, w0 = 1.0f - lx;
+  const float v00 = xt[(size_t)(y0 * TW + x0) * E + c], v01 = xt[(size_t)(y0 * TW + x0 + xp) * E + c];
+  const float v10 = xt[(size_t)((y0 + yp) * TW + x0) * E + c], v11 = xt[(size_t)((y0 + yp) * TW + x0 + xp) * E + c];
+  return h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11);
+}
+
+void ita_oracle_tail_general(const float* x2, int B, int E, int TH, int TW, int CO, const float* cw, const float* cb,
+                             float* out, float* t_fused /* optional (B, 5E/4, 2TH, 2TW) */) {
+  const int C4 = E / 4, CIN = C4 + E, OH = 2 * TH, OW = 2 * TW;
   float* fused = (float*)malloc(sizeof(float) * (size_t)CIN * OH * OW);
   for (int b = 0; b < B; ++b) {
-    const float* xt = x2 + (size_t)b * 128 * E; /* [token = h*16+w][c] */
-    for (int c = 0; c < C4; ++c)
+    const float* xt = x2 + (size_t)b * TH * TW * E; /* [token = h*TW+w][c] */
+    for (int c = 0; c < CIN; ++c)
       for (int y = 0; y < OH; ++y)
-        for (int x = 0; x < OW; ++x) {
-          const int h = y >> 1, a = y & 1, w = x >> 1, bb = x & 1;
-          fused[((size_t)c * OH + y) * OW + x] = xt[(size_t)(h * TOK_W + w) * E + (4 * c + 2 * a + bb)];
-        }
-    for (int c = 0; c < E; ++c)
-      for (int y = 0; y < OH; ++y) {
-        int y0, yp; float ly;
-        upsample_src_ac(y, TOK_H, OH, &y0, &yp, &ly);
-        for (int x = 0; x < OW; ++x) {
-          int x0, xp; float lx;
-          upsample_src_ac(x, TOK_W, OW, &x0, &xp, &lx);
-          const float h1 = ly, h0 = 1.0f - ly, w1 = lx, w0 = 1.0f - lx;
-          const float v00 = xt[(size_t)(y0 * TOK_W + x0) * E + c], v01 = xt[(size_t)(y0 * TOK_W + x0 + xp) * E + c];
-          const float v10 = xt[(size_t)((y0 + yp) * TOK_W + x0) * E + c];
-          const float v11 = xt[(size_t)((y0 + yp) * TOK_W + x0 + xp) * E + c];
-          fused[((size_t)(C4 + c) * OH + y) * OW + x] = h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11);
-        }
-      }
+        for (int x = 0; x < OW; ++x) fused[((size_t)c * OH + y) * OW + x] = tail_fused_at(xt, E, TH, TW, c, y, x);
     if (t_fused) memcpy(t_fused + (size_t)b * CIN * OH * OW, fused, sizeof(float) * (size_t)CIN * OH * OW);
-    for (int o = 0; o < 9; ++o)
+    for (int o = 0; o < CO; ++o)
       for (int y = 0; y < OH; ++y)
         for (int x = 0; x < OW; ++x) {
           float acc = cb[o];
@@ -354,10 +353,36 @@ void ita_oracle_tail(const float* x2, int B, int E, const float* cw, const float
                 if (iy < 0 || iy >= OH || ix < 0 || ix >= OW) continue;
                 acc = fmaf(fused[((size_t)c * OH + iy) * OW + ix], cw[(((size_t)o * CIN + c) * 3 + ky) * 3 + kx], acc);
               }
-          feat[(size_t)b * 9 * OH * OW + ((size_t)o * OH + y) * OW + x] = acc;
+          out[(((size_t)b * CO + o) * OH + y) * OW + x] = acc;
         }
   }
   free(fused);
+}
+
+/* the same outputs at n sampled positions pts[i] = {b, o, y, x} (for checks at sizes where the full map
+ * would take minutes on one core) */
+void ita_oracle_tail_general_at(const float* x2, int E, int TH, int TW, int CO, const float* cw, const float* cb,
+                                const int* pts, int n, float* vals) {
+  const int CIN = E / 4 + E, OH = 2 * TH, OW = 2 * TW;
+  (void)CO;
+  for (int i = 0; i < n; ++i) {
+    const int b = pts[4 * i], o = pts[4 * i + 1], y = pts[4 * i + 2], x = pts[4 * i + 3];
+    const float* xt = x2 + (size_t)b * TH * TW * E;
+    float acc = cb[o];
+    for (int c = 0; c < CIN; ++c)
+      for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) {
+          const int iy = y + ky - 1, ix = x + kx - 1;
+          if (iy < 0 || iy >= OH || ix < 0 || ix >= OW) continue;
+          acc = fmaf(tail_fused_at(xt, E, TH, TW, c, iy, ix), cw[(((size_t)o * CIN + c) * 3 + ky) * 3 + kx], acc);
+        }
+    vals[i] = acc;
+  }
+}
+
+void ita_oracle_tail(const float* x2, int B, int E, const float* cw, const float* cb, float* feat,
+                     float* t_fused /* optional (B, 5E/4, 16, 32) */) {
+  ita_oracle_tail_general(x2, B, E, TOK_H, TOK_W, 9, cw, cb, feat, t_fused);
 }
 
 /* ------------------------------------------------------------------ float linear / LSTM */

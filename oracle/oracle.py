@@ -125,6 +125,29 @@ def tail(x2, cw, cb, want_fused=False):
     return (feat, fused) if want_fused else feat
 
 
+def tail_general(x2, tok_h, tok_w, cw, cb, want_fused=False):
+    """fusion tail on a tok_h x tok_w token grid, cw (CO, 5E/4, 3, 3) -> (B, CO, 2 tok_h, 2 tok_w)  (BASELINE config 5)"""
+    x2 = _c(x2, np.float32)
+    B, T, E = x2.shape
+    assert T == tok_h * tok_w
+    cw = _c(cw, np.float32)
+    CO = cw.shape[0]
+    out = np.empty((B, CO, 2 * tok_h, 2 * tok_w), np.float32)
+    fused = np.empty((B, E // 4 + E, 2 * tok_h, 2 * tok_w), np.float32) if want_fused else None
+    lib().ita_oracle_tail_general(_p(x2), B, E, tok_h, tok_w, CO, _p(cw), _p(_c(cb, np.float32)), _p(out), _p(fused))
+    return (out, fused) if want_fused else out
+
+
+def tail_general_at(x2, tok_h, tok_w, cw, cb, pts):
+    """the same map sampled at pts (n, 4) int32 rows (b, o, y, x)"""
+    x2, cw = _c(x2, np.float32), _c(cw, np.float32)
+    pts = _c(pts, np.int32)
+    vals = np.empty(len(pts), np.float32)
+    lib().ita_oracle_tail_general_at(_p(x2), x2.shape[-1], tok_h, tok_w, cw.shape[0], _p(cw), _p(_c(cb, np.float32)),
+                                     _p(pts), len(pts), _p(vals))
+    return vals
+
+
 def linear_f32(x, w, b):
     x, w = _c(x, np.float32), _c(w, np.float32)
     rows, K, N = x.size // x.shape[-1], x.shape[-1], w.shape[0]

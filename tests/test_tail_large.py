@@ -1,0 +1,125 @@
+"""Fusion tail on large token grids (BASELINE config 5).
+
+CPU: the generalised oracle (oracle/ita_oracle.c:ita_oracle_tail_general) against outputs of the torch layers the
+reference declares (tests/golden/tail_large_*.npz, tools/gen_golden.py:gen_tail_large): <= 2e-5 absolute (PyTorch's
+conv summation order is not the oracle's), and its sampled form against the full form (equality).
+GPU (-m gpu): ita_fusion_tail_large through the C ABI against the oracle.  The kernel runs the convolution on
+split-precision f16 MFMA (three products, f32 accumulate): tolerance 2e-5 relative to the largest output magnitude,
+stated at the assertion (the task's bound for this tail is 1e-4).
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_files
+from drone_oa_iree_vit_accelerator_amd import host, params, synth
+
+FIX = golden_files("tail_large_*.npz")
+
+
+def _case(path):
+    d = params.load_fixture(path)
+    meta = {k: int(d[k]) for k in ("seed", "E", "tok_h", "tok_w", "out_ch", "B")}
+    c = synth.tail_large_case(meta["seed"], meta["E"], meta["tok_h"], meta["tok_w"], meta["out_ch"], meta["B"])
+    assert synth.digest(c) == str(d["inputs_sha256"]), "synth.tail_large_case drifted from the committed fixture"
+    return meta, c, d["out"]
+
+
+def test_fixtures_present():
+    assert len(FIX) >= 2
+
+
+@pytest.mark.parametrize("path", FIX, ids=[p.split("/")[-1][:-4] for p in FIX])
+def test_oracle_general_tail_vs_torch_layers(oracle, path):
+    meta, c, want = _case(path)
+    got = oracle.tail_general(c["x"], meta["tok_h"], meta["tok_w"], c["conv_w"], c["conv_b"])
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 2e-5
+
+
+def test_oracle_general_equals_model_tail(oracle):
+    """on the model's own 8 x 16 grid with 9 outputs the general form IS ita_oracle_tail"""
+    c = synth.tail_large_case(7, 64, 8, 16, 9, 2)
+    a = oracle.tail_general(c["x"], 8, 16, c["conv_w"], c["conv_b"])
+    b = oracle.tail(c["x"], c["conv_w"], c["conv_b"])
+    assert np.array_equal(a.reshape(2, -1), b)
+
+
+def test_oracle_sampled_equals_full(oracle):
+    c = synth.tail_large_case(3, 128, 4, 16, 48, 2)
+    full = oracle.tail_general(c["x"], 4, 16, c["conv_w"], c["conv_b"])
+    rs = np.random.RandomState(0)
+    pts = np.stack([rs.randint(0, 2, 300), rs.randint(0, 48, 300), rs.randint(0, 8, 300), rs.randint(0, 32, 300)], 1)
+    pts[:8] = [[0, 0, 0, 0], [1, 47, 7, 31], [0, 5, 0, 31], [1, 9, 7, 0], [0, 1, 3, 0], [0, 2, 0, 5], [1, 3, 7, 9], [0, 4, 4, 31]]
+    vals = oracle.tail_general_at(c["x"], 4, 16, c["conv_w"], c["conv_b"], pts.astype(np.int32))
+    assert np.array_equal(vals, full[pts[:, 0], pts[:, 1], pts[:, 2], pts[:, 3]])
+
+
+# ------------------------------------------------------------------------------------------ GPU
+def _run(torch, c, th, tw):
+    eng = host.FusionTailLarge(c["conv_w"], c["conv_b"], device=0)
+    out = eng(torch.from_numpy(c["x"]).cuda(), th, tw)
+    torch.cuda.synchronize()
+    res = out.cpu().numpy()
+    eng.close()
+    return res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(128, 4, 16, 48, 2), (64, 8, 16, 9, 3), (128, 8, 32, 16, 1), (64, 4, 16, 33, 2)],
+                         ids=["E128_4x16_co48", "E64_8x16_co9", "E128_8x32_co16", "E64_4x16_co33"])
+def test_gpu_tail_large_vs_oracle(oracle, shape):
+    import torch
+    E, th, tw, co, B = shape
+    c = synth.tail_large_case(11, E, th, tw, co, B)
+    want = oracle.tail_general(c["x"], th, tw, c["conv_w"], c["conv_b"])
+    got = _run(torch, c, th, tw)
+    assert got.shape == want.shape
+    tol = 2e-5 * np.abs(want).max()      # f16x3 MFMA vs the f32 fmaf chain; task bound 1e-4
+    assert np.abs(got - want).max() <= tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FIX, ids=[p.split("/")[-1][:-4] for p in FIX])
+def test_gpu_tail_large_vs_golden(path):
+    import torch
+    meta, c, want = _case(path)
+    got = _run(torch, c, meta["tok_h"], meta["tok_w"])
+    assert np.abs(got - want).max() <= 4e-5 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.gpu
+def test_gpu_tail_config5_size(oracle):
+    """BASELINE config 5's map (64 x 128 tokens, E = 128, 48 outputs; 2.26 G MAC per frame): sampled oracle
+    comparison, run-to-run determinism, and independence of a frame's result from its batch position."""
+    import torch
+    E, th, tw, co, B = 128, 64, 128, 48, 2
+    c = synth.tail_large_case(5, E, th, tw, co, B)
+    eng = host.FusionTailLarge(c["conv_w"], c["conv_b"], device=0)
+    x = torch.from_numpy(c["x"]).cuda()
+    a = eng(x, th, tw)
+    b = eng(x, th, tw)
+    sw = eng(x.flip(0).contiguous(), th, tw)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert torch.equal(a, sw.flip(0))
+    got = a.cpu().numpy()
+    rs = np.random.RandomState(1)
+    n = 1500
+    pts = np.stack([rs.randint(0, B, n), rs.randint(0, co, n), rs.randint(0, 2 * th, n), rs.randint(0, 2 * tw, n)], 1)
+    pts[:6] = [[0, 0, 0, 0], [1, 47, 127, 255], [0, 7, 0, 255], [1, 8, 127, 0], [0, 20, 64, 128], [1, 33, 63, 31]]
+    want = oracle.tail_general_at(c["x"], th, tw, c["conv_w"], c["conv_b"], pts.astype(np.int32))
+    err = np.abs(got[pts[:, 0], pts[:, 1], pts[:, 2], pts[:, 3]] - want).max()
+    assert err <= 2e-5 * max(1.0, np.abs(want).max())
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_gpu_tail_large_rejects_bad_shapes():
+    import torch
+    c = synth.tail_large_case(0, 64, 4, 16, 9, 1)
+    eng = host.FusionTailLarge(c["conv_w"], c["conv_b"], device=0)
+    with pytest.raises(host.ITAError):
+        eng(torch.zeros((1, 3 * 16, 64), device="cuda"), 3, 16)      # tok_h % 4
+    with pytest.raises(host.ITAError):
+        eng(torch.zeros((1, 4 * 8, 64), device="cuda"), 4, 8)        # tok_w % 16
+    eng.close()

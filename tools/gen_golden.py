@@ -286,6 +286,29 @@ def gen_softmax(out_dir):
     print("wrote softmax fixtures", x.shape)
 
 
+def gen_tail_large(out_dir):
+    """BASELINE config 5 / SURVEY.md section 8(d): the fusion-tail layers on a larger token grid with E = 128 and
+    48 conv outputs -- nn.PixelShuffle(2), nn.Upsample(bilinear, align_corners=True) and nn.Conv2d(160, 48, 3,
+    padding=1) exactly as the reference declares them (models/ITA_upsample_shuffle/model.py:70-78) and wires them
+    (models/ITA_single_layer_upsample_shuffle/QAT/model.py:116-121); seeded inputs from synth.tail_large_case, only
+    the expected output is stored."""
+    synth = _load_synth()
+    for (seed, E, th, tw, co, B) in ((0, 128, 4, 16, 48, 2), (1, 64, 8, 16, 9, 1)):
+        c = synth.tail_large_case(seed, E, th, tw, co, B)
+        x = torch.from_numpy(c["x"])
+        x2d = x.transpose(1, 2).reshape(B, E, th, tw)
+        up = torch.nn.Upsample(size=(2 * th, 2 * tw), mode="bilinear", align_corners=True)
+        conv = torch.nn.Conv2d(E // 4 + E, co, 3, padding=1)
+        with torch.no_grad():
+            conv.weight.copy_(torch.from_numpy(c["conv_w"]))
+            conv.bias.copy_(torch.from_numpy(c["conv_b"]))
+            out = conv(torch.cat([torch.nn.PixelShuffle(2)(x2d), up(x2d)], dim=1))
+        name = f"tail_large_E{E}_T{th}x{tw}_CO{co}_s{seed}.npz"   # (not "*_seed*": that glob selects the int8 block fixtures)
+        np.savez_compressed(os.path.join(out_dir, name), out=out.numpy(), seed=seed, E=E, tok_h=th, tok_w=tw,
+                            out_ch=co, B=B, inputs_sha256=synth.digest(c))
+        print("wrote", name, tuple(out.shape))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
@@ -297,6 +320,7 @@ def main():
     for seed in (0, 1):
         gen_blocks(seed, 128, 1, a.out)
     gen_blocks(2, 64, 1, a.out, gain_qk=6.0)
+    gen_tail_large(a.out)
 
 
 if __name__ == "__main__":
