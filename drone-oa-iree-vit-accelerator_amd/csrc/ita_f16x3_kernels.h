@@ -379,9 +379,10 @@ __global__ void ita_impulse_kernel(float* x, int rows, int width, int col0) {
 // implicit GEMM on split-precision f16 MFMA (hi + lo operand planes, three products, f32 accumulate --
 // the same scheme and error, ~2^-22 relative, as ita_gemm_f16x3_kernel), never materialising the
 // 160-channel concatenated map:
-//   workgroup = 4 waves = one 8 x 32 output tile, all output channels; wave w owns rows 2w, 2w+1 as four
+//   workgroup = WAVES (8, or 4 when the map height is not a multiple of 16) waves = one (2 WAVES) x 32 output
+//   tile, all output channels; two waves per SIMD cover each other's LDS latency; wave w owns rows 2w, 2w+1 as four
 //   16-pixel M tiles x NT 16-channel N tiles of v_mfma_f32_16x16x32_f16;
-//   K loop: channel chunks of 32 x 9 taps; per chunk the 10 x 34 halo of the concatenated map is BUILT in
+//   K loop: channel chunks of 32 x 9 taps; per chunk the halo of the concatenated map is BUILT in
 //   LDS from the tokens (shuffle gather / exact f32 bilinear blend, then split into f16 hi + lo,
 //   pixel-major [pixel][32 ch]) next to the chunk's weights [tap][co][32 ch] (prepared at load time).
 struct ItaTailBigArgs {
@@ -392,22 +393,25 @@ struct ItaTailBigArgs {
   float* out;                     // (B, CO, 2TH, 2TW)
   int B, E, TH, TW, CO, nchunk;
 };
-template <int NT>
+template <int NT, int WAVES>
 struct ItaTailBigLds {
-  static constexpr int HP = 10 * 34;                       // halo pixels of an 8 x 32 tile
+  static constexpr int HP = (2 * WAVES + 2) * 34;          // halo pixels of a (2 WAVES) x 32 tile
   static constexpr int A_PLANE = HP * 64;                  // [pixel][32 ch] f16
   static constexpr int W_PLANE = 9 * NT * 16 * 64;         // [tap][co][32 ch] f16
   static constexpr int AH = 0, AL = A_PLANE, WH = 2 * A_PLANE, WL = WH + W_PLANE;
-  static constexpr int TOTAL = WL + W_PLANE;
+  static constexpr int GEO_I = WL + W_PLANE;               // per halo pixel: {upsample offset, shuffle offset, flags, -}
+  static constexpr int GEO_F = GEO_I + HP * 16;            // per halo pixel: {h1, w1}
+  static constexpr int TOTAL = GEO_F + HP * 8;
 };
 
-template <int NT>
-__global__ __launch_bounds__(256) void ita_tail_big_kernel(const ItaTailBigArgs a) {
-  using L = ItaTailBigLds<NT>;
+template <int NT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void ita_tail_big_kernel(const ItaTailBigArgs a) {
+  using L = ItaTailBigLds<NT, WAVES>;
+  constexpr int NTHR = 64 * WAVES;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int OH = 2 * a.TH, OW = 2 * a.TW, C4 = a.E / 4, CIN = C4 + a.E;
-  const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 8, b = blockIdx.z;
+  const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 2 * WAVES, b = blockIdx.z;
   const float* xt = a.x + (size_t)b * a.TH * a.TW * a.E;
   const float sy = (float)(a.TH - 1) / (float)(OH - 1), sx = (float)(a.TW - 1) / (float)(OW - 1);
 
@@ -417,57 +421,93 @@ __global__ __launch_bounds__(256) void ita_tail_big_kernel(const ItaTailBigArgs 
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
+  // ---- per halo pixel, once per tile: where its shuffle source and its four bilinear sources sit in x, the
+  // two interpolation weights, validity.  (Recomputing this for every (chunk, channel quad) cost more VALU
+  // time than the MFMAs of the chunk.)
+  for (int p = tid; p < L::HP; p += NTHR) {
+    const int hy = p / 34, hx = p - 34 * hy;
+    const int y = ty0 + hy - 1, x = tx0 + hx - 1;
+    const int ok = (y >= 0 && y < OH && x >= 0 && x < OW) ? 4 : 0;
+    const int yc = min(max(y, 0), OH - 1), xc = min(max(x, 0), OW - 1);
+    const float fy = sy * (float)yc, fx = sx * (float)xc;   // bilinear x2, align_corners=True
+    int y0 = (int)fy, x0 = (int)fx;
+    if (y0 > a.TH - 1) y0 = a.TH - 1;
+    if (x0 > a.TW - 1) x0 = a.TW - 1;
+    const int yp = y0 < a.TH - 1 ? 2 : 0, xp = x0 < a.TW - 1 ? 1 : 0;
+    *(i32x4*)(lds + L::GEO_I + p * 16) = (i32x4){(y0 * a.TW + x0) * a.E,
+                                                   ((yc >> 1) * a.TW + (xc >> 1)) * a.E + 2 * (yc & 1) + (xc & 1), ok | yp | xp, 0};
+    *(f32x2*)(lds + L::GEO_F + p * 8) = (f32x2){fy - (float)y0, fx - (float)x0};
+  }
+
   for (int ch = 0; ch < a.nchunk; ++ch) {
-    __syncthreads();   // the previous chunk's fragments are consumed
-    // ---- weights of this chunk: a straight 16-byte copy (already in fragment order)
+    __syncthreads();   // the previous chunk's fragments are consumed (first pass: the geometry table is complete)
+    // ---- weights of this chunk: already in fragment order -> a straight LDS-DMA copy (global_load_lds_dwordx4,
+    // 1 KB per wave instruction, asynchronous: all of it is in flight while the halo is built below)
     {
-      const i32x4* gh = (const i32x4*)(a.w_hi + (size_t)ch * (L::W_PLANE / 2));
-      const i32x4* gl = (const i32x4*)(a.w_lo + (size_t)ch * (L::W_PLANE / 2));
-      for (int i = tid; i < L::W_PLANE / 16; i += 256) {
-        *(i32x4*)(lds + L::WH + 16 * i) = gh[i];
-        *(i32x4*)(lds + L::WL + 16 * i) = gl[i];
+      const _Float16* gh = a.w_hi + (size_t)ch * (L::W_PLANE / 2);
+      const _Float16* gl = a.w_lo + (size_t)ch * (L::W_PLANE / 2);
+      for (int wc = wave; wc < L::W_PLANE / 1024; wc += WAVES) {
+        const int piece = wc * 64 + lane;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gh + piece * 8),
+                                         (__attribute__((address_space(3))) void*)(lds + L::WH + wc * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gl + piece * 8),
+                                         (__attribute__((address_space(3))) void*)(lds + L::WL + wc * 1024), 16, 0, 0);
       }
     }
-    // ---- halo of the concatenated map, channels 32ch .. 32ch+31: thread = (pixel, 4 channels)
-    for (int i = tid; i < L::HP * 8; i += 256) {
-      const int p = i >> 3, cq = i & 7;
-      const int hy = p / 34, hx = p - 34 * hy;
-      const int y = ty0 + hy - 1, x = tx0 + hx - 1;
-      const int c0 = ch * 32 + 4 * cq;
-      float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (y >= 0 && y < OH && x >= 0 && x < OW && c0 < CIN) {
-        if (c0 < C4) {   // PixelShuffle(2): out[c][2h+i][2w+j] = in[4c+2i+j][h][w]
-          const float* t = xt + (size_t)((y >> 1) * a.TW + (x >> 1)) * a.E + 2 * (y & 1) + (x & 1);
+    // ---- halo of the concatenated map, channels 32ch .. 32ch+31: thread = (pixel, 4 channels).  Items are
+    // processed G at a time with every global load of the group issued (from clamped, always valid addresses)
+    // before the first use: one memory latency per group instead of one per item.
+    {
+      constexpr int G = 5, NITEM = L::HP * 8;
+      const bool all_shuffle = ch * 32 + 31 < C4, all_up = ch * 32 >= C4;
+      for (int i0 = tid; i0 < NITEM; i0 += NTHR * G) {
+        f32x4 q00[G], q01[G], q10[G], q11[G];
+        f32x2 hw[G];
+        int item[G];
+        bool ok[G];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = (c0 + j < C4) ? t[4 * (c0 + j)] : 0.0f;
+        for (int g = 0; g < G; ++g) {
+          const int i = min(i0 + NTHR * g, NITEM - 1);
+          const int p = i >> 3, cq = i & 7;
+          const int c0 = ch * 32 + 4 * cq;
+          const i32x4 gi = *(const i32x4*)(lds + L::GEO_I + p * 16);
+          hw[g] = *(const f32x2*)(lds + L::GEO_F + p * 8);
+          item[g] = i;
+          ok[g] = i0 + NTHR * g < NITEM && (gi.z & 4) && c0 < CIN;
+          if (all_shuffle || (!all_up && c0 < C4)) {   // PixelShuffle(2): out[c][2h+i][2w+j] = in[4c+2i+j][h][w]
+            const float* t = xt + gi.y + 4 * min(c0, C4 - 4);
+            q00[g] = (f32x4){t[0], t[4], t[8], t[12]};
+            q01[g] = q10[g] = q11[g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+          } else {
+            const float* t00 = xt + gi.x + min(max(c0 - C4, 0), a.E - 4);
+            const int dx = (gi.z & 1) ? a.E : 0, dy = (gi.z & 2) ? a.TW * a.E : 0;
+            q00[g] = *(const f32x4*)t00;
+            q01[g] = *(const f32x4*)(t00 + dx);
+            q10[g] = *(const f32x4*)(t00 + dy);
+            q11[g] = *(const f32x4*)(t00 + dy + dx);
+          }
         }
-        if (c0 + 3 >= C4) {   // bilinear x2, align_corners=True (ita_tail_kernel's / the oracle's expression)
-          const float fy = sy * (float)y, fx = sx * (float)x;
-          int y0 = (int)fy, x0 = (int)fx;
-          if (y0 > a.TH - 1) y0 = a.TH - 1;
-          if (x0 > a.TW - 1) x0 = a.TW - 1;
-          const int yp = y0 < a.TH - 1 ? 1 : 0, xp = x0 < a.TW - 1 ? 1 : 0;
-          const float h1 = fy - (float)y0, h0 = 1.0f - h1, w1 = fx - (float)x0, w0 = 1.0f - w1;
-          const float* t00 = xt + (size_t)(y0 * a.TW + x0) * a.E;
-          const float* t01 = t00 + (size_t)xp * a.E;
-          const float* t10 = t00 + (size_t)yp * a.TW * a.E;
-          const float* t11 = t10 + (size_t)xp * a.E;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int c = c0 + j - C4;
-            if (c >= 0 && c < a.E) v[j] = h0 * (w0 * t00[c] + w1 * t01[c]) + h1 * (w0 * t10[c] + w1 * t11[c]);
+        for (int g = 0; g < G; ++g) {
+          if (i0 + NTHR * g < NITEM) {
+            const int p = item[g] >> 3, cq = item[g] & 7;
+            const bool shuf = all_shuffle || (!all_up && ch * 32 + 4 * cq < C4);
+            const float h1 = hw[g].x, h0 = 1.0f - h1, w1 = hw[g].y, w0 = 1.0f - w1;
+            f16x4 vh, vl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              // (ita_tail_kernel's / the oracle's expression; the shuffle branch passes its value through)
+              float v = shuf ? q00[g][j] : h0 * (w0 * q00[g][j] + w1 * q01[g][j]) + h1 * (w0 * q10[g][j] + w1 * q11[g][j]);
+              if (!ok[g]) v = 0.0f;
+              _Float16 hq, lq;
+              split_f16(v, hq, lq);
+              vh[j] = hq; vl[j] = lq;
+            }
+            *(f16x4*)(lds + L::AH + p * 64 + cq * 8) = vh;
+            *(f16x4*)(lds + L::AL + p * 64 + cq * 8) = vl;
           }
         }
       }
-      f16x4 vh, vl;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        _Float16 q, r;
-        split_f16(v[j], q, r);
-        vh[j] = q; vl[j] = r;
-      }
-      *(f16x4*)(lds + L::AH + p * 64 + cq * 8) = vh;
-      *(f16x4*)(lds + L::AL + p * 64 + cq * 8) = vl;
     }
     __syncthreads();
     // ---- 9 taps x (4 M tiles x NT N tiles) x 3 products; A lane = (pixel l&15, channels 8(l>>4)..+7)

@@ -326,17 +326,24 @@ int launch_gemm(const float* A, int lda, const float* W, int ldw, const float* b
   return ITA_OK;
 }
 
-template <int NT>
-int launch_tail_big(ita_context* c, const ItaTailBigArgs& a, hipStream_t s) {
+template <int NT, int WAVES>
+int launch_tail_big_w(const ItaTailBigArgs& a, hipStream_t s) {
   static bool attr_set = false;
+  auto kern = ita_tail_big_kernel<NT, WAVES>;
+  constexpr int lds_bytes = ItaTailBigLds<NT, WAVES>::TOTAL;
   if (!attr_set) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(ita_tail_big_kernel<NT>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, ItaTailBigLds<NT>::TOTAL));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     attr_set = true;
   }
-  hipLaunchKernelGGL(ita_tail_big_kernel<NT>, dim3(2 * a.TW / 32, 2 * a.TH / 8, a.B), dim3(256), ItaTailBigLds<NT>::TOTAL, s, a);
+  hipLaunchKernelGGL(kern, dim3(2 * a.TW / 32, 2 * a.TH / (2 * WAVES), a.B), dim3(64 * WAVES), lds_bytes, s, a);
   HIPCHK(hipGetLastError());
   return ITA_OK;
+}
+// 16-row tiles (8 waves) when the map height allows, else 8-row tiles (4 waves)
+template <int NT>
+int launch_tail_big(ita_context* c, const ItaTailBigArgs& a, hipStream_t s) {
+  (void)c;
+  return (2 * a.TH) % 16 == 0 ? launch_tail_big_w<NT, 8>(a, s) : launch_tail_big_w<NT, 4>(a, s);
 }
 
 template <int BM, int BN, int WM, int WN>
