@@ -123,7 +123,8 @@ def main():
     if a.image_dtype == "u8":
         img = torch.from_numpy(fr["img_u8"]).to(dev)
     else:
-        img = (torch.from_numpy(fr["img_u8"]).to(dev).float() / 255.0).contiguous()
+        # the reference host's float(pixel) / 255.0f (main.cpp:168-169), IEEE division on the CPU
+        img = torch.from_numpy(fr["img_u8"].astype(np.float32) / np.float32(255.0)).to(dev)
     dv, qt = torch.from_numpy(fr["desvel"]).to(dev), torch.from_numpy(fr["quat"]).to(dev)
     state = [(torch.zeros((3, B, 128), device=dev), torch.zeros((3, B, 128), device=dev)) for _ in range(2)]
     vels = [torch.empty((B, 3), device=dev) for _ in range(2)]
@@ -244,7 +245,7 @@ def main():
             "value": round(world * B * K / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(elapsed / K * 1e3, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int8+f32", "data": "synthetic",
-            "config": {"workload": "ITAViTLSTM int8 end-to-end forward (BASELINE config 4): 1024 synthetic 60x90 "
+            "config": {"workload": f"ITAViTLSTM int8 end-to-end forward (BASELINE config 4): {B} synthetic 60x90 "
                                    "depth frames per GPU per step, LSTM state carried, velocity all-gather",
                        "frames_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "image_dtype": a.image_dtype, "weights": "seed-0 synthetic QAT (tests/golden)",

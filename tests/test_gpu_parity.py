@@ -246,6 +246,35 @@ def test_full_size_properties(torch_cuda, oracle):
     eng.close()
 
 
+@pytest.mark.parametrize("B", [1, 3, 257, 300])
+def test_fused_tokenizer_path_equals_split_path(torch_cuda, oracle, B):
+    """u8 wire frames take the kernel with the tokenizer fused in front of the encoder layer; f32 frames take the
+    separate tokenizer launch.  Both must give the same bits (tokens, x1, x2, state, velocity), for batch sizes
+    below, at and above the number of workgroups (256 CUs: frames 256.. are a workgroup's second frame)."""
+    torch = torch_cuda
+    d = params.load_fixture(FIX_VIT[0])
+    eng, blob, fp = _engine(d, 64)
+    fr = synth.frames(900 + B, B)
+    cu = lambda a: torch.from_numpy(a).cuda()
+    img8 = cu(fr["img_u8"])
+    # float(pixel) / 255.0f as the reference host computes it (main.cpp:168-169): IEEE division, done in numpy
+    # (a GPU-side torch division is not guaranteed to be correctly rounded)
+    imgf = cu(fr["img_u8"].astype(np.float32) / np.float32(255.0))
+    dv, qt = cu(fr["desvel"]), cu(fr["quat"])
+    va, (ha, ca), ta = eng.forward(img8, dv, qt, taps=True)
+    vb, (hb, cb), tb = eng.forward(imgf, dv, qt, taps=True)
+    for k in ("tokens", "x1", "x2"):
+        assert torch.equal(ta[k], tb[k]), k
+    assert torch.equal(va, vb) and torch.equal(ha, hb) and torch.equal(ca, cb)
+    assert torch.equal(ta["tokens"], eng.tokenizer(img8))
+    sel = sorted({0, B - 1, B // 2})
+    otok = oracle.tokenizer(fr["img_u8"][sel].astype(np.float32) / np.float32(255.0),
+                            fp["tokenizer.conv.weight"].reshape(64, 49), fp["tokenizer.conv.bias"],
+                            fp["tokenizer.norm.weight"], fp["tokenizer.norm.bias"])
+    np.testing.assert_array_equal(ta["tokens"].cpu().numpy()[sel], otok)
+    eng.close()
+
+
 @pytest.mark.parametrize("dtype", ["f16", "f32"])
 def test_dropin_symbol_host_buffers(torch_cuda, oracle, dtype):
     """ITASelfAttention_workgroup(in, out) with the reference's prototype: host buffers of
