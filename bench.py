@@ -143,6 +143,8 @@ def main():
         back(i-1), same stream) and the buffer reuse (front(i) after back(i-2)) are ordered by events."""
         src, dst = state[i & 1], state[(i + 1) & 1]
         vel = vels[i & 1]
+        if world > 1:
+            gather.ready()      # the all-gather of step i-2 read this velocity buffer
         if not pipelined:
             eng.forward(img, dv, qt, src, out=(vel, dst[0], dst[1]))
             if world > 1:

@@ -64,6 +64,13 @@ class VelocityGather:
         self.handles = [None, None]
         self.i = 0
 
+    def ready(self):
+        """Call before overwriting the `vel` tensor that was passed to `start` two steps ago (callers that
+        ping-pong two velocity buffers in step with this object): its all-gather may still be reading it."""
+        if self.handles[self.i] is not None:
+            self.handles[self.i].wait()
+            self.handles[self.i] = None
+
     def start(self, vel):
         import torch.distributed as dist
         i = self.i
