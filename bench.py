@@ -268,6 +268,18 @@ def main():
                 torch.cuda.synchronize()
                 lat.append(time.perf_counter() - t1)
             out["p50_latency_ms_b1"] = round(float(np.median(lat[50:])) * 1e3, 4)
+            # the same step replayed from a HIP graph (six launches -> one host call), in-place state
+            g1 = e1.graphed_step(1)
+            g1.img.copy_(i1); g1.desvel.copy_(d1.reshape(1)); g1.quat.copy_(q1)
+            lat = []
+            for it in range(250):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                g1()
+                torch.cuda.synchronize()
+                lat.append(time.perf_counter() - t1)
+            out["p50_latency_ms_b1_hipgraph"] = round(float(np.median(lat[50:])) * 1e3, 4)
+            del g1
             e1.close()
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(blob)

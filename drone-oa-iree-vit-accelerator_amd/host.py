@@ -358,9 +358,53 @@ class Engine:
                                              state_h.shape[1], vel.data_ptr(), B, _stream_ptr()))
         return vel
 
+    def graphed_step(self, batch: int) -> "GraphedStep":
+        """a HIP-graph replay of one time step with static buffers (see GraphedStep)"""
+        _chk(lib().ita_reserve(self._h, batch))
+        return GraphedStep(self, batch)
+
     # ---- drop-in symbols (host buffers) --------------------------------------------------
     def bind_dispatch(self, layer: int = 0, dtype: int = DISPATCH_F16):
         _chk(lib().ita_bind_dispatch(self._h, layer, dtype))
+
+
+class GraphedStep:
+    """One time step of ita_vitlstm_forward captured in a HIP graph: at small batch the six kernel launches
+    are launch-bound, a graph replays them with one host call.  Static buffers: write `img` (B,60,90) u8,
+    `desvel` (B,), `quat` (B,4), then call the object; `vel` (B,3) holds the result, the LSTM state `h`, `c`
+    (3,B,128) is updated in place from step to step (zero it to start a new stream)."""
+
+    def __init__(self, engine: "Engine", batch: int):
+        torch = _torch()
+        dev = torch.device("cuda", engine.device)
+        self.engine, self.B = engine, batch
+        self.img = torch.zeros((batch, 60, 90), dtype=torch.uint8, device=dev)
+        self.desvel = torch.zeros((batch,), dtype=torch.float32, device=dev)
+        self.quat = torch.zeros((batch, 4), dtype=torch.float32, device=dev)
+        self.quat[:, 0] = 1
+        self.h = torch.zeros((3, batch, 128), dtype=torch.float32, device=dev)
+        self.c = torch.zeros((3, batch, 128), dtype=torch.float32, device=dev)
+        self.vel = torch.zeros((batch, 3), dtype=torch.float32, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):          # warm-up outside the capture: workspace, kernel attributes
+            for _ in range(2):
+                self._step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.h.zero_()
+        self.c.zero_()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._step()
+        self.h.zero_()
+        self.c.zero_()
+
+    def _step(self):
+        self.engine.forward(self.img, self.desvel, self.quat, (self.h, self.c), out=(self.vel, self.h, self.c))
+
+    def __call__(self):
+        self.graph.replay()
+        return self.vel
 
 
 class FusionTailLarge:

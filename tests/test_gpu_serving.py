@@ -134,3 +134,21 @@ def test_front_back_pipeline_equals_forward():
         assert torch.equal(outs[t], ref[t][0]), t
         assert torch.equal(hs[t][0], ref[t][1]) and torch.equal(hs[t][1], ref[t][2]), t
     eng.close()
+
+
+def test_graphed_step_equals_eager_forward():
+    """the HIP-graph replay of a time step (in-place state, static buffers) gives the bits of the eager calls"""
+    import torch
+    eng = host.Engine(_blob(), device=0)
+    for B in (1, 5):
+        fr = [synth.frames(40 + t, B) for t in range(3)]
+        g = eng.graphed_step(B)
+        st = (torch.zeros((3, B, 128), device="cuda"), torch.zeros((3, B, 128), device="cuda"))
+        for t in range(3):
+            img, dv, qt = (torch.from_numpy(fr[t][k]).cuda() for k in ("img_u8", "desvel", "quat"))
+            g.img.copy_(img); g.desvel.copy_(dv.reshape(B)); g.quat.copy_(qt)
+            vg = g().clone()
+            ve, st = eng.forward(img, dv, qt, st)
+            assert torch.equal(vg, ve), (B, t)
+            assert torch.equal(g.h, st[0]) and torch.equal(g.c, st[1])
+    eng.close()
