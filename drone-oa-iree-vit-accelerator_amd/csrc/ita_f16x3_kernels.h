@@ -393,20 +393,22 @@ struct ItaTailBigArgs {
   float* out;                     // (B, CO, 2TH, 2TW)
   int B, E, TH, TW, CO, nchunk;
 };
-template <int NT, int WAVES>
+template <int NT, int WAVES, int TPS>
 struct ItaTailBigLds {
   static constexpr int HP = (2 * WAVES + 2) * 34;          // halo pixels of a (2 WAVES) x 32 tile
   static constexpr int A_PLANE = HP * 64;                  // [pixel][32 ch] f16
-  static constexpr int W_PLANE = 9 * NT * 16 * 64;         // [tap][co][32 ch] f16
+  static constexpr int W_PLANE = TPS * NT * 16 * 64;       // [tap (TPS of the 9 at a time)][co][32 ch] f16
   static constexpr int AH = 0, AL = A_PLANE, WH = 2 * A_PLANE, WL = WH + W_PLANE;
   static constexpr int GEO_I = WL + W_PLANE;               // per halo pixel: {upsample offset, shuffle offset, flags, -}
   static constexpr int GEO_F = GEO_I + HP * 16;            // per halo pixel: {h1, w1}
   static constexpr int TOTAL = GEO_F + HP * 8;
 };
 
-template <int NT, int WAVES>
+template <int NT, int WAVES, int TPS>
 __global__ __launch_bounds__(64 * WAVES) void ita_tail_big_kernel(const ItaTailBigArgs a) {
-  using L = ItaTailBigLds<NT, WAVES>;
+  using L = ItaTailBigLds<NT, WAVES, TPS>;
+  static_assert(9 % TPS == 0, "taps per weight stage must divide 9");
+  constexpr int W_CHUNK_HALVES = 9 * NT * 16 * 32;   // f16 elements of one channel chunk's weights per plane in global
   constexpr int NTHR = 64 * WAVES;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -441,11 +443,12 @@ __global__ __launch_bounds__(64 * WAVES) void ita_tail_big_kernel(const ItaTailB
 
   for (int ch = 0; ch < a.nchunk; ++ch) {
     __syncthreads();   // the previous chunk's fragments are consumed (first pass: the geometry table is complete)
-    // ---- weights of this chunk: already in fragment order -> a straight LDS-DMA copy (global_load_lds_dwordx4,
-    // 1 KB per wave instruction, asynchronous: all of it is in flight while the halo is built below)
-    {
-      const _Float16* gh = a.w_hi + (size_t)ch * (L::W_PLANE / 2);
-      const _Float16* gl = a.w_lo + (size_t)ch * (L::W_PLANE / 2);
+    // ---- weights: already in fragment order -> a straight LDS-DMA copy (global_load_lds_dwordx4, 1 KB per wave
+    // instruction, asynchronous).  TPS of the chunk's 9 taps are resident at a time: with TPS = 3 the workgroup
+    // needs 70 KB of LDS and TWO of them share a CU -- one builds its halo while the other runs MFMAs.
+    auto stage_w = [&](int tap0) {
+      const _Float16* gh = a.w_hi + (size_t)ch * W_CHUNK_HALVES + (size_t)tap0 * NT * 16 * 32;
+      const _Float16* gl = a.w_lo + (size_t)ch * W_CHUNK_HALVES + (size_t)tap0 * NT * 16 * 32;
       for (int wc = wave; wc < L::W_PLANE / 1024; wc += WAVES) {
         const int piece = wc * 64 + lane;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gh + piece * 8),
@@ -453,7 +456,8 @@ __global__ __launch_bounds__(64 * WAVES) void ita_tail_big_kernel(const ItaTailB
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gl + piece * 8),
                                          (__attribute__((address_space(3))) void*)(lds + L::WL + wc * 1024), 16, 0, 0);
       }
-    }
+    };
+    stage_w(0);
     // ---- halo of the concatenated map, channels 32ch .. 32ch+31: thread = (pixel, 4 channels).  Items are
     // processed G at a time with every global load of the group issued (from clamped, always valid addresses)
     // before the first use: one memory latency per group instead of one per item.
@@ -514,11 +518,16 @@ __global__ __launch_bounds__(64 * WAVES) void ita_tail_big_kernel(const ItaTailB
     const int px = lane & 15, kg = lane >> 4;
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
-      const int ky = tap / 3, kx = tap - 3 * ky;
+      if (TPS < 9 && tap > 0 && tap % TPS == 0) {
+        __syncthreads();     // the resident taps are consumed
+        stage_w(tap);
+        __syncthreads();     // (hipcc drains the LDS-DMA, vmcnt(0), ahead of the barrier)
+      }
+      const int ky = tap / 3, kx = tap - 3 * ky, tl = tap % TPS;
       f16x8 bh[NT], bl[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const int off = ((tap * NT * 16 + nt * 16 + px) * 64) + kg * 16;
+        const int off = ((tl * NT * 16 + nt * 16 + px) * 64) + kg * 16;
         bh[nt] = *(const f16x8*)(lds + L::WH + off);
         bl[nt] = *(const f16x8*)(lds + L::WL + off);
       }

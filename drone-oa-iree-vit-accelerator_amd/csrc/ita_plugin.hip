@@ -326,11 +326,11 @@ int launch_gemm(const float* A, int lda, const float* W, int ldw, const float* b
   return ITA_OK;
 }
 
-template <int NT, int WAVES>
+template <int NT, int WAVES, int TPS>
 int launch_tail_big_w(const ItaTailBigArgs& a, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = ita_tail_big_kernel<NT, WAVES>;
-  constexpr int lds_bytes = ItaTailBigLds<NT, WAVES>::TOTAL;
+  auto kern = ita_tail_big_kernel<NT, WAVES, TPS>;
+  constexpr int lds_bytes = ItaTailBigLds<NT, WAVES, TPS>::TOTAL;
   if (!attr_set) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     attr_set = true;
@@ -339,11 +339,16 @@ int launch_tail_big_w(const ItaTailBigArgs& a, hipStream_t s) {
   HIPCHK(hipGetLastError());
   return ITA_OK;
 }
-// 16-row tiles (8 waves) when the map height allows, else 8-row tiles (4 waves)
+// 16-row tiles on 8 waves with a whole chunk's weights resident when the map height allows (measured best:
+// 0.61 ms for 32 frames of BASELINE config 5); else 8-row tiles on 4 waves with a third of the chunk's taps
+// resident (70 KB of LDS, two workgroups per CU: 0.66 ms).  ITA_TAIL_BIG=2 / 3 force the 4-wave forms.
 template <int NT>
 int launch_tail_big(ita_context* c, const ItaTailBigArgs& a, hipStream_t s) {
   (void)c;
-  return (2 * a.TH) % 16 == 0 ? launch_tail_big_w<NT, 8>(a, s) : launch_tail_big_w<NT, 4>(a, s);
+  static const int mode = getenv("ITA_TAIL_BIG") ? atoi(getenv("ITA_TAIL_BIG")) : 0;
+  if (mode == 2) return launch_tail_big_w<NT, 4, 9>(a, s);
+  if (mode == 3 || (2 * a.TH) % 16 != 0) return launch_tail_big_w<NT, 4, 3>(a, s);
+  return launch_tail_big_w<NT, 8, 9>(a, s);
 }
 
 template <int BM, int BN, int WM, int WN>
