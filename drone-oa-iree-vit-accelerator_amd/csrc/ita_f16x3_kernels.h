@@ -162,6 +162,51 @@ __global__ __launch_bounds__(64 * WM * WN) void ita_gemm_f16x3_kernel(const ItaG
     }
 }
 
+// ---- the same GEMM for small M (a few frames: the reference's real deployment is ONE drone, M = 1).
+// ita_gemm_f16x3_kernel needs M >= 1024 to fill the chip and, at M = 1, still walks its 16 k-tiles with one
+// exposed memory latency each (22 us).  Here one wave owns one 32 x 32 output tile of one K slice and streams its
+// fragments straight from L2 into an 8-slot register ring (7 k-steps in flight); grid (N/32, ceil(M/32), nsplit).
+// Per output element the arithmetic is IDENTICAL to the large kernel's -- the same v_mfma_f32_32x32x16_f16 on the
+// same operand values in the same lane slots, k-steps in the same order, the same three products per step -- so a
+// frame's result does not depend on which of the two kernels served its batch (tests: a 5-frame batch against
+// rows of a 1024-frame batch, bit for bit).
+__global__ __launch_bounds__(64) void ita_gemm_f16x3_small_kernel(const ItaGemmSplitArgs g) {
+  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32, z = blockIdx.z;
+  const int kslice = g.K / g.nsplit, kbeg = z * kslice, nstep = kslice / 16;
+  const size_t ao = (size_t)min(m0 + r, g.M - 1) * g.lda + kbeg + 8 * h;
+  const size_t wo = (size_t)(n0 + r) * g.ldw + kbeg + 8 * h;
+  constexpr int R = 8;
+  f16x8 ah[R], al[R], wh[R], wl[R];
+  auto fetch = [&](int s, int slot) {
+    ah[slot] = *(const f16x8*)(g.a_hi + ao + 16 * s);
+    al[slot] = *(const f16x8*)(g.a_lo + ao + 16 * s);
+    wh[slot] = *(const f16x8*)(g.w_hi + wo + 16 * s);
+    wl[slot] = *(const f16x8*)(g.w_lo + wo + 16 * s);
+  };
+#pragma unroll
+  for (int s = 0; s < R; ++s) fetch(s, s);
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+  for (int s0 = 0; s0 < nstep; s0 += R) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j], wh[j], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], wl[j], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], wh[j], acc, 0, 0, 0);
+      if (s0 + R + j < nstep) fetch(s0 + R + j, j);
+    }
+  }
+  // C layout: col n = lane&31, row m = (e&3) + 8*(e>>2) + 4*h
+  float* out = g.out + (size_t)z * g.M * g.N;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int m = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+    if (m < g.M) out[(size_t)m * g.N + n0 + r] = acc[e];
+  }
+}
+
 // ------------------------------------------------------------------ LSTM layer 0
 // The decoder Linear feeds nothing but LSTM layer 0 (QAT/model.py:124-128), so its weights are folded
 // one step further at load time:  G0 = W_ih0[:, :512] . Wfold  (512 x 8192).  The big GEMM then

@@ -357,6 +357,12 @@ int launch_gemm_split(const _Float16* a_hi, const _Float16* a_lo, int lda, const
   if (N % BN || K % (64 * nsplit)) return fail(ITA_ERR_UNSUPPORTED, "split gemm shape");
   static const int dbg = getenv("ITA_GEMM_DBG") ? atoi(getenv("ITA_GEMM_DBG")) : 0;
   ItaGemmSplitArgs g{a_hi, a_lo, lda, w_hi, w_lo, ldw, out, M, N, K, nsplit, dbg};
+  static const int small_max = getenv("ITA_GEMM_SMALL_MAX") ? atoi(getenv("ITA_GEMM_SMALL_MAX")) : 128;
+  if (M <= small_max && N % 32 == 0) {   // a few frames: one wave per 32 x 32 tile and K slice, same arithmetic
+    hipLaunchKernelGGL(ita_gemm_f16x3_small_kernel, dim3(N / 32, (M + 31) / 32, nsplit), dim3(64), 0, s, g);
+    HIPCHK(hipGetLastError());
+    return ITA_OK;
+  }
   constexpr int lds_bytes = ItaGemmSplitLds<BM, BN>::TOTAL;
   auto kern = ita_gemm_f16x3_kernel<BM, BN, WM, WN>;
   hipLaunchKernelGGL(kern, dim3((N / BN) * ((M + BM - 1) / BM) * nsplit), dim3(64 * WM * WN), lds_bytes, s, g);
