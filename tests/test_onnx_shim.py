@@ -1,0 +1,177 @@
+"""ONNX entry shim.  No `onnx` package and no file from the reference's exporter
+exist here, so the marker graph is BUILT below with a minimal protobuf writer, following the graph that
+tests/export_onnx_for_FPGA.py:71-80 exports from models/ITA_single_layer_upsample_shuffle/export/model.py
+(op lowering of the TorchScript exporter at opset 17; ONNX LSTM gate order i, o, f, c), and the shim must recognise
+it and hand back exactly the float parameters it was built from -- parity with a real export is unpinned."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from drone_oa_iree_vit_accelerator_amd import onnx_shim, params, synth
+
+
+# ------------------------------------------------------------------ minimal protobuf writer (test side only)
+def _vi(v):
+    v &= (1 << 64) - 1
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _ld(fno, payload):
+    return _vi(fno << 3 | 2) + _vi(len(payload)) + payload
+
+
+def _iv(fno, v):
+    return _vi(fno << 3 | 0) + _vi(v)
+
+
+def _tensor(name, arr, raw=True):
+    arr = np.ascontiguousarray(arr)
+    dt = {np.dtype(np.float32): 1, np.dtype(np.int64): 7}[arr.dtype]
+    b = b"".join(_iv(1, d) for d in arr.shape) + _iv(2, dt)
+    if raw:
+        b += _ld(9, arr.tobytes())
+    elif dt == 1:
+        b += _ld(4, arr.astype("<f4").tobytes())            # packed float_data
+    else:
+        b += _ld(7, b"".join(_vi(int(x)) for x in arr.ravel()))
+    return b + _ld(8, name.encode())
+
+
+def _attr(name, v):
+    b = _ld(1, name.encode())
+    if isinstance(v, int):
+        return b + _iv(3, v) + _iv(20, 2)
+    if isinstance(v, float):
+        return b + _vi(2 << 3 | 5) + struct.pack("<f", v) + _iv(20, 1)
+    if isinstance(v, (bytes, str)):
+        return b + _ld(4, v if isinstance(v, bytes) else v.encode()) + _iv(20, 3)
+    return b + _ld(8, b"".join(_vi(int(x)) for x in v)) + _iv(20, 7)   # ints, packed
+
+
+def _node(op, ins, outs, **attrs):
+    b = b"".join(_ld(1, i.encode()) for i in ins) + b"".join(_ld(2, o.encode()) for o in outs)
+    b += _ld(4, op.encode()) + b"".join(_ld(5, _attr(k, v)) for k, v in attrs.items())
+    return b
+
+
+def _vinfo(name, shape):
+    dims = b"".join(_ld(1, _iv(1, d)) for d in shape)
+    return _ld(1, name.encode()) + _ld(2, _ld(1, _iv(1, 1) + _ld(2, dims)))
+
+
+def _onnx_lstm_order(w):          # PyTorch i, f, g, o -> ONNX i, o, f, c
+    H = w.shape[0] // 4
+    i, f, g, o = (w[k * H:(k + 1) * H] for k in range(4))
+    return np.concatenate([i, o, f, g], axis=0)
+
+
+def build_marker_onnx(fp, E=64, marker="addself", opset=17, inputs=onnx_shim.IO_INPUTS, raw=True, drop_marker=False):
+    init, nodes = [], []
+    t = lambda name, arr: (init.append(_tensor(name, arr, raw)), name)[1]
+    N = lambda *a, **k: nodes.append(_node(*a, **k))
+    N("Conv", ["image", t("tokenizer.conv.weight", fp["tokenizer.conv.weight"]), t("tokenizer.conv.bias", fp["tokenizer.conv.bias"])],
+      ["conv0"], dilations=[1, 1], group=1, kernel_shape=[7, 7], pads=[3, 3, 3, 3], strides=[2, 2])
+    N("Resize", ["conv0", "", "", t("onnx::Resize_9", np.array([1, E, 8, 16], np.int64))], ["res0"], mode="linear",
+      coordinate_transformation_mode="pytorch_half_pixel")
+    N("Reshape", ["res0", t("onnx::Reshape_12", np.array([1, E, 128], np.int64))], ["flat0"])
+    N("Transpose", ["flat0"], ["tok0"], perm=[0, 2, 1])
+    N("LayerNormalization", ["tok0", t("tokenizer.norm.weight", fp["tokenizer.norm.weight"]), t("tokenizer.norm.bias", fp["tokenizer.norm.bias"])],
+      ["x0"], axis=-1, epsilon=1e-5)
+    x = "x0"
+    for blk, key in (("attn", "norms1.0"), ("ffn", "norms2.0")):
+        if not (drop_marker and blk == "ffn"):
+            if marker == "addself":
+                N("Add", [x, x], [blk + "_out"])
+            else:
+                N("Neg" if blk == "attn" else "Abs", [x], [blk + "_out"])
+        else:
+            N("Identity", [x], [blk + "_out"])
+        N("Add", [x, blk + "_out"], [blk + "_res"])
+        N("LayerNormalization", [blk + "_res", t(key + ".weight", fp[key + ".weight"]), t(key + ".bias", fp[key + ".bias"])],
+          [blk + "_ln"], axis=-1, epsilon=1e-5)
+        x = blk + "_ln"
+    N("Transpose", [x], ["xt"], perm=[0, 2, 1])
+    N("Reshape", ["xt", t("onnx::Reshape_40", np.array([1, E, 8, 16], np.int64))], ["x2d"])
+    N("DepthToSpace", ["x2d"], ["shuf"], blocksize=2, mode="CRD")
+    N("Resize", ["x2d", "", "", t("onnx::Resize_44", np.array([1, E, 16, 32], np.int64))], ["ups"], mode="linear",
+      coordinate_transformation_mode="align_corners")
+    N("Concat", ["shuf", "ups"], ["fused"], axis=1)
+    N("Conv", ["fused", t("down_sample.weight", fp["down_sample.weight"]), t("down_sample.bias", fp["down_sample.bias"])], ["down"],
+      dilations=[1, 1], group=1, kernel_shape=[3, 3], pads=[1, 1, 1, 1], strides=[1, 1])
+    N("Flatten", ["down"], ["feat"], axis=1)
+    N("Gemm", ["feat", t("decoder.weight", fp["decoder.weight"]), t("decoder.bias", fp["decoder.bias"])], ["dec"], alpha=1.0,
+      beta=1.0, transB=1)
+    N("Div", ["additional_data", t("onnx::Div_50", np.array([10.0], np.float32))], ["dv"])
+    N("Concat", ["dec", "dv", "quat_data"], ["cat"], axis=1)
+    N("Unsqueeze", ["cat", t("onnx::Unsqueeze_53", np.array([0], np.int64))], ["seq0"])
+    seq = "seq0"
+    for l in range(3):
+        W = _onnx_lstm_order(fp[f"lstm.weight_ih_l{l}"])[None]
+        R = _onnx_lstm_order(fp[f"lstm.weight_hh_l{l}"])[None]
+        B = np.concatenate([_onnx_lstm_order(fp[f"lstm.bias_ih_l{l}"]), _onnx_lstm_order(fp[f"lstm.bias_hh_l{l}"])])[None]
+        N("LSTM", [seq, t(f"onnx::LSTM_{100 + 3 * l}", W), t(f"onnx::LSTM_{101 + 3 * l}", R), t(f"onnx::LSTM_{102 + 3 * l}", B), "",
+                   f"h_in{l}", f"c_in{l}"], [f"y{l}", f"h{l}", f"c{l}"], hidden_size=128)
+        N("Squeeze", [f"y{l}", t(f"onnx::Squeeze_{200 + l}", np.array([1], np.int64))], [f"seq{l + 1}"])
+        seq = f"seq{l + 1}"
+    N("Squeeze", [seq, t("onnx::Squeeze_210", np.array([0], np.int64))], ["last"])
+    if raw:
+        N("Gemm", ["last", t("nn_fc2.weight", fp["nn_fc2.weight"]), t("nn_fc2.bias", fp["nn_fc2.bias"])], ["output"], alpha=1.0,
+          beta=1.0, transB=1)
+    else:       # the other lowering of nn.Linear: MatMul with the transposed weight, then Add
+        N("MatMul", ["last", t("onnx::MatMul_220", np.ascontiguousarray(fp["nn_fc2.weight"].T))], ["mm"])
+        N("Add", [t("nn_fc2.bias", fp["nn_fc2.bias"]), "mm"], ["output"])
+    N("Concat", ["h0", "h1", "h2"], ["hidden_out_h"], axis=0)
+    N("Concat", ["c0", "c1", "c2"], ["hidden_out_c"], axis=0)
+    shapes = {"image": [1, 1, 60, 90], "additional_data": [1, 1], "quat_data": [1, 4], "hidden_in_h": [3, 1, 128],
+              "hidden_in_c": [3, 1, 128]}
+    g = b"".join(_ld(1, n) for n in nodes) + _ld(2, b"main_graph") + b"".join(_ld(5, i) for i in init)
+    g += b"".join(_ld(11, _vinfo(n, shapes.get(n, [1]))) for n in inputs)
+    g += b"".join(_ld(12, _vinfo(n, s)) for n, s in (("output", [1, 3]), ("hidden_out_h", [3, 1, 128]), ("hidden_out_c", [3, 1, 128])))
+    return _iv(1, 8) + _ld(2, b"pytorch") + _ld(7, g) + _ld(8, _ld(1, b"") + _iv(2, opset))
+
+
+# ------------------------------------------------------------------ tests
+FLOAT_KEYS = [k for k in synth.float_params(0, E=64) if not k.startswith(("attention_blocks", "ffn_blocks"))]
+
+
+@pytest.mark.parametrize("raw", [True, False], ids=["raw_data_gemm", "typed_data_matmul"])
+def test_marker_graph_recognised_and_weights_recovered(raw):
+    fp = synth.float_params(3, E=64)
+    info = onnx_shim.match_itavitlstm(onnx_shim.parse_model(build_marker_onnx(fp, raw=raw)))
+    assert info["E"] == 64 and info["num_layers"] == 1 and len(info["markers"]) == 2
+    assert sorted(info["float_params"]) == sorted(FLOAT_KEYS)
+    for k in FLOAT_KEYS:
+        assert np.array_equal(info["float_params"][k], fp[k]), k       # incl. the LSTM gate re-ordering
+
+
+def test_neg_abs_markers_and_blob():
+    """the E = 128 block exports mark attention with neg and feed-forward with abs (ITA_ONNX.py:26,38); the recovered
+    float half plus the int8 record of a converted checkpoint gives the same blob as the original parameters"""
+    fp = synth.float_params(0, E=64)
+    info = onnx_shim.match_itavitlstm(onnx_shim.parse_model(build_marker_onnx(fp, marker="negabs")))
+    assert len(info["markers"]) == 2
+    fx = params.load_fixture(os.path.join(os.path.dirname(__file__), "golden", "vitlstm_E64_seed0_B2.npz"))
+    assert params.blob_from_record(fx, info["float_params"], E=64) == params.blob_from_record(fx, fp, E=64)
+
+
+def test_violations_are_reported():
+    fp = synth.float_params(1, E=64)
+    with pytest.raises(onnx_shim.OnnxShimError, match="inputs"):
+        onnx_shim.match_itavitlstm(onnx_shim.parse_model(build_marker_onnx(
+            fp, inputs=("img", "additional_data", "quat_data", "hidden_in_h", "hidden_in_c"))))
+    with pytest.raises(onnx_shim.OnnxShimError, match="opset"):
+        onnx_shim.match_itavitlstm(onnx_shim.parse_model(build_marker_onnx(fp, opset=13)))
+    with pytest.raises(onnx_shim.OnnxShimError, match="marker"):
+        onnx_shim.match_itavitlstm(onnx_shim.parse_model(build_marker_onnx(fp, drop_marker=True)))
+    with pytest.raises(onnx_shim.OnnxShimError):
+        onnx_shim.parse_model(b"\x0a\xff\xff")                        # truncated field
+    with pytest.raises(onnx_shim.OnnxShimError, match="no graph"):
+        onnx_shim.parse_model(_iv(1, 8))
