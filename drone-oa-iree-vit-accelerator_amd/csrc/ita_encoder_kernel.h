@@ -20,6 +20,8 @@
 #pragma once
 #include "ita_int8_kernels.h"
 
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
 struct ItaEncArgs {
   const float* x;        // (B,128,64)
   float* y;              // (B,128,64) f32, may be null when planes are given
@@ -382,8 +384,8 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
     lds_barrier();
     ITA_STAMP(1);
 
-    // ---------------- phase P: Q, K, V projections.  Each wave owns token tile tt and nine feature tiles
-    // (waves 0-3: Q0-5, K0-2; waves 4-7: K3-5, V0-5), processed TWO AT A TIME: both tiles' fragment reads
+    // ---------------- phase P: Q, K, V projections.  Each wave owns token tile tt and eleven or seven feature tiles
+    // (waves 0-3: Q0-5, K0-4; waves 4-7: K5, V0-5), processed TWO AT A TIME: both tiles' fragment reads
     // and MFMAs are issued before either epilogue, so the VALU-heavy requantisation of one tile overlaps
     // the LDS/MFMA latency of the other (the wave has only one SIMD partner to hide latency behind).
     {
@@ -416,32 +418,30 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
         const int d = dt * 32 + r;
         unsigned p4[4];
         rq_pack16(acc, a.mv, -128.0f, p4);
+        // p4[g] belongs to slot kq = 2*(g&1) + h at word t = 2*(tt&1) + (g>>1): words g and g+2 are adjacent
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int kb = tt >> 1, kq = 2 * (g & 1) + h, t = 2 * (tt & 1) + (g >> 1);
-          *(unsigned*)(lds + L::VT + (((kb * 4 + kq) * P + d) << 4) + 4 * t) = p4[g];
+        for (int gq = 0; gq < 2; ++gq) {
+          const int kb = tt >> 1, kq = 2 * gq + h;
+          *(u32x2*)(lds + L::VT + (((kb * 4 + kq) * P + d) << 4) + 8 * (tt & 1)) = (u32x2){p4[gq], p4[gq + 2]};
         }
         int csum = sum_bytes16(p4);
         csum += xor32_i(csum);
         if (h == 0) atomicAdd(&colsum[d], csum << 7);   // kept pre-multiplied by the 128 offset
       };
+      // A V tile costs ~1.6x a Q/K tile (scattered 4-byte V^T writes, column sums), measured with the per-wave
+      // arrival stamps: waves 0-3 take eleven Q/K tiles, waves 4-7 one K tile and the six V tiles.
       if (wave < 4) {
 #pragma unroll 1
-        for (int ft = 0; ft < 8; ft += 2) {          // (Q0,Q1) (Q2,Q3) (Q4,Q5) (K0,K1)
+        for (int ft = 0; ft < 10; ft += 2) {         // (Q0,Q1) (Q2,Q3) (Q4,Q5) (K0,K1) (K2,K3)
           const int m0 = ft / 6, d0 = ft - 6 * m0, m1 = (ft + 1) / 6, d1 = ft + 1 - 6 * m1;
           const i32x16 a0 = qk_acc(m0, d0), a1 = qk_acc(m1, d1);
           qk_store(a0, m0, d0);
           qk_store(a1, m1, d1);
         }
-        qk_store(qk_acc(1, 2), 1, 2);                 // K2
+        qk_store(qk_acc(1, 4), 1, 4);                 // K4
       } else {
         {
-          const i32x16 a0 = qk_acc(1, 3), a1 = qk_acc(1, 4);
-          qk_store(a0, 1, 3);
-          qk_store(a1, 1, 4);
-        }
-        {
-          const i32x16 a0 = qk_acc(1, 5), a1 = v_acc(0);
+          const i32x16 a0 = qk_acc(1, 5), a1 = v_acc(0);   // K5, V0
           qk_store(a0, 1, 5);
           v_store(a1, 0);
         }
@@ -454,6 +454,8 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
         v_store(v_acc(5), 5);
       }
     }
+    if (a.stamps && fi < 8 && (tid == 0 || tid == 256))     // diagnostic: arrival of waves 0 and 4 at the barrier
+      a.stamps[((size_t)blockIdx.x * 8 + fi) * 16 + 13 + (tid >> 8)] = __builtin_amdgcn_s_memtime();
     lds_barrier();
     ITA_STAMP(2);
 

@@ -165,7 +165,8 @@ int ita_fusion_tail_large(ita_handle h, const float* x_dev, float* out_dev, int 
 /* Diagnostic: one encoder layer with in-kernel s_memtime stamps (wave 0 of every workgroup, its
  * first 8 frames, 16 slots): stamps[(block * 8 + frame) * 16 + slot], u64 device buffer of
  * min(batch, #CUs) * 128 entries.  Slots 0..8: the phase boundaries of the frame; with image_u8_dev
- * (tokenizer fused in front, x_dev unused) slots 9..12: the steps of tokenizing the NEXT frame.
+ * (tokenizer fused in front, x_dev unused) slots 9..12: the steps of tokenizing the NEXT frame; slots 13, 14:
+ * arrival of waves 0 and 4 at the barrier that ends the projection phase.
  * Not used by the product path. */
 int ita_debug_encoder_stamps(ita_handle h, int layer, const float* x_dev, const void* image_u8_dev, float* y_dev,
                              int batch, unsigned long long* stamps_dev, void* stream);

@@ -24,6 +24,9 @@ for i, n in enumerate(names):
     print(f"  {n:16s} median {np.median(dt[..., i]):9.0f}  p90 {np.percentile(dt[..., i], 90):9.0f}")
 tot = frames[..., 8] - frames[..., 0]
 print(f"  frame total      median {np.median(tot):9.0f}")
+w0, w4 = frames[..., 13] - frames[..., 1], frames[..., 14] - frames[..., 1]
+# the two waves share a SIMD: what counts is their sum (the phase is VALU-issue bound), not their balance
+print(f"  phase P work: wave 0 (11 Q/K tiles) median {np.median(w0):7.0f}, wave 4 (1 K + 6 V tiles) median {np.median(w4):7.0f}")
 if fused:
     tk = frames[..., [8, 9, 10, 11, 12]]
     for i, n in enumerate(["T0+T1 image/weights -> LDS", "T2 blend", "T3 MFMA", "T4 LayerNorm"]):
