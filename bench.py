@@ -114,9 +114,10 @@ def main():
                          "f32: the graph's own input type (separate tokenizer launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
-    ap.add_argument("--pipeline", action="store_true", help="two streams: step t+1's image-only front "
-                    "(ita_vitlstm_front) overlaps step t's LSTM back (ita_vitlstm_back); measured gain ~2 %, "
-                    "default is one stream with ita_vitlstm_forward per step")
+    ap.add_argument("--pipeline", action="store_true", help="two streams: step t's LSTM back (ita_vitlstm_back) runs "
+                    "next to the folded GEMM of step t+1's image-only front (ita_vitlstm_front_ev).  Measured: +3 %% at 2048 "
+                    "and 4096 frames per GPU; at 1024 the extra Python stream / event calls make the host the bottleneck "
+                    "(slower than the default, which is one stream with ita_vitlstm_forward per step)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' only to "
                     "rehearse the N>1 code path with several ranks on one GPU (set ITA_FORCE_DEVICE=0)")
     a = ap.parse_args()
@@ -159,7 +160,11 @@ def main():
     sf, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
     ev_front = [torch.cuda.Event() for _ in range(2)]
     ev_back = [torch.cuda.Event() for _ in range(2)]
+    ev_enc = [torch.cuda.Event() for _ in range(2)]
+    for e in ev_enc:
+        e.record()          # creates the HIP event behind it (its handle is passed through the C ABI)
     started = [False, False]
+    pending = [None]        # pipelined schedule: the step whose back half has not been enqueued yet
     dvf = dv.reshape(B).contiguous()
     torch.cuda.synchronize()
 
@@ -169,9 +174,9 @@ def main():
         back(i-1), same stream) and the buffer reuse (front(i) after back(i-2)) are ordered by events."""
         src, dst = state[i & 1], state[(i + 1) & 1]
         vel = vels[i & 1]
-        if world > 1:
-            gather.ready()      # the all-gather of step i-2 read this velocity buffer
         if not pipelined:
+            if world > 1:
+                gather.ready()      # the all-gather of step i-2 read this velocity buffer
             eng.forward(img, dv, qt, src, out=(vel, dst[0], dst[1]))
             if world > 1:
                 gather.start(vel)
@@ -179,15 +184,32 @@ def main():
         buf = i & 1
         if started[buf]:
             sf.wait_event(ev_back[buf])
-        eng.front(img, buf, stream=sf)
+        eng.front(img, buf, stream=sf, encoder_done=ev_enc[buf])
         ev_front[buf].record(sf)
+        # the back of the PREVIOUS step goes next to this step's GEMM: next to the encoder (one persistent workgroup
+        # per CU, all LDS and VGPRs) it would only delay some of the encoder's workgroups
+        if pending[0] is not None:
+            run_back(pending[0], ev_enc[buf])
+        pending[0] = (i, buf, src, dst, vel)
+
+    def run_back(job, after):
+        j, buf, src, dst, vel = job
         sb.wait_event(ev_front[buf])
-        eng.back(dvf, qt, src, (vel, dst[0], dst[1]), buf, stream=sb)
-        ev_back[buf].record(sb)
-        started[buf] = True
-        if world > 1:
-            with torch.cuda.stream(sb):
+        if after is not None:
+            sb.wait_event(after)
+        with torch.cuda.stream(sb):
+            if world > 1:
+                gather.ready()      # the all-gather of step j-2 read this velocity buffer
+            eng.back(dvf, qt, src, (vel, dst[0], dst[1]), buf, stream=sb)
+            ev_back[buf].record(sb)
+            started[buf] = True
+            if world > 1:
                 gather.start(vel)
+
+    def flush():
+        if pending[0] is not None:
+            run_back(pending[0], None)
+            pending[0] = None
 
     def fence():
         torch.cuda.synchronize()
@@ -197,6 +219,7 @@ def main():
 
     for i in range(W):
         step(i)
+    flush()
     gather.finish()
     fence()
     # Untimed pass with HIP events around EVERY stage: the per-stage table and the dominant stage.
@@ -225,6 +248,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(K):
         step(W + NP + i)
+    flush()
     gather.finish()
     fence()
     elapsed = time.perf_counter() - t0

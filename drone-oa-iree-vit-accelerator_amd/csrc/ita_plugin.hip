@@ -925,7 +925,8 @@ int ita_vitlstm_forward(ita_handle h, const void* image, int image_dtype, const 
 }
 
 // ---- two-stage form for software pipelining across time steps -------------------------------------
-int ita_vitlstm_front(ita_handle h, const void* image, int image_dtype, int batch, int buf, void* stream) {
+static int front_impl(ita_handle h, const void* image, int image_dtype, int batch, int buf, void* stream,
+                      void* encoder_done_event) {
   int rc = check(h, batch);
   if (rc) return rc;
   if (!image || (buf != 0 && buf != 1)) return fail(ITA_ERR_INVALID_ARG, "null image or buf not in {0,1}");
@@ -955,12 +956,22 @@ int ita_vitlstm_front(ita_handle h, const void* image, int image_dtype, int batc
                              nullptr, batch, s, nullptr, nullptr, nullptr, nullptr, (fused_tok && l == 0) ? image : nullptr))) return rc;
   }
   if ((rc = mark(1, true)) || (rc = mark(3, false))) return rc;
+  if (encoder_done_event) HIPCHK(hipEventRecord((hipEvent_t)encoder_done_event, s));
   float* part = h->part + (size_t)buf * NSPLIT * h->cap * 512;
   if ((rc = launch_gemm_split<128, 128, 2, 4>(h->x2_hi, h->x2_lo, LDFOLD, h->fold_hi, h->fold_lo, LDFOLD, part, batch, 512,
                                               KFOLD, NSPLIT, s))) return rc;
   if ((rc = mark(3, true))) return rc;
   if (ev && (h->prof_stage == 0 || h->prof_stage == 1 || h->prof_stage == 3)) ++h->prof_n;
   return ITA_OK;
+}
+
+int ita_vitlstm_front(ita_handle h, const void* image, int image_dtype, int batch, int buf, void* stream) {
+  return front_impl(h, image, image_dtype, batch, buf, stream, nullptr);
+}
+
+int ita_vitlstm_front_ev(ita_handle h, const void* image, int image_dtype, int batch, int buf, void* stream,
+                         void* encoder_done_event) {
+  return front_impl(h, image, image_dtype, batch, buf, stream, encoder_done_event);
 }
 
 int ita_vitlstm_back(ita_handle h, const float* desvel, const float* quat, const float* h_in, const float* c_in, float* vel,
@@ -975,11 +986,13 @@ int ita_vitlstm_back(ita_handle h, const float* desvel, const float* quat, const
   const int B = batch;
   const size_t lstride = (size_t)B * 128;
   const float* part = h->part + (size_t)buf * NSPLIT * h->cap * 512;
-  // layer 0 reads whole rows of h while other workgroups overwrite parts of them when h_out aliases h_in
-  HIPCHK(hipMemcpyAsync(h->gates, h_in, sizeof(float) * lstride, hipMemcpyDeviceToDevice, s));
+  // layer 0 reads whole rows of h while other workgroups overwrite parts of them when h_out aliases h_in:
+  // only then is its h staged (a copy; ita_vitlstm_forward does this inside the encoder kernel)
+  const bool stage_h0 = h_out < h_in + lstride && h_in < h_out + lstride;
+  if (stage_h0) HIPCHK(hipMemcpyAsync(h->gates, h_in, sizeof(float) * lstride, hipMemcpyDeviceToDevice, s));
   {
     ItaLstm0Args p{part, NSPLIT, h->fold_inv_scale, h->lw_hi[0], h->lw_lo[0], h->lw_inv_scale[0], h->fold_bias, desvel, quat,
-                   h->gates, c_in, h_out, c_out, h->c1_hi, h->c1_lo, h_in + lstride, B, nullptr};
+                   stage_h0 ? h->gates : h_in, c_in, h_out, c_out, h->c1_hi, h->c1_lo, h_in + lstride, B, nullptr};
     hipLaunchKernelGGL(ita_lstm0_kernel<NSPLIT>, dim3(16, (B + 31) / 32), dim3(64), 0, s, p);
     HIPCHK(hipGetLastError());
   }

@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = (
     "ita_profile_begin", "ita_profile_begin_sampled", "ita_profile_end", "ita_set_tail_mode", "ita_debug_encoder_stamps",
     "ita_fusion_tail_load", "ita_fusion_tail_large",
     "ita_wire_unpack_packet", "ita_wire_postprocess", "ita_vitlstm_forward_slots", "ita_vitlstm_front",
-    "ita_vitlstm_back",
+    "ita_vitlstm_back", "ita_vitlstm_front_ev",
     "ITASelfAttention_workgroup", "ITASelfAttention_workgroup_expanded", "ITAFeedForward_workgroup",
 )
 
@@ -114,6 +114,7 @@ def lib():
         L.ita_vitlstm_forward.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, vp, vp, i, C.POINTER(_FwdTaps), vp]
         L.ita_vitlstm_forward_slots.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, i, vp, i, vp]
         L.ita_vitlstm_front.argtypes = [vp, vp, i, i, i, vp]
+        L.ita_vitlstm_front_ev.argtypes = [vp, vp, i, i, i, vp, vp]
         L.ita_vitlstm_back.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp]
         L.ita_bind_dispatch.argtypes = [vp, i, i]
         L.ita_wire_unpack_packet.argtypes = [vp, C.c_size_t, i, vp]
@@ -328,11 +329,14 @@ class Engine:
         _chk(lib().ita_profile_end(self._h, ms, C.byref(n)))
         return dict(zip(self.STAGES, list(ms))), n.value
 
-    def front(self, img, buf: int, stream=None):
-        """image-only half of a time step (tokenizer, encoder, folded GEMM) into internal buffer `buf`"""
+    def front(self, img, buf: int, stream=None, encoder_done=None):
+        """image-only half of a time step (tokenizer, encoder, folded GEMM) into internal buffer `buf`;
+        encoder_done: optional torch.cuda.Event (already recorded once, so that its handle exists) recorded between
+        the encoder and the GEMM"""
         img, dt = self._image(img)
         sp = _stream_ptr() if stream is None else C.c_void_p(stream.cuda_stream)
-        _chk(lib().ita_vitlstm_front(self._h, img.data_ptr(), dt, img.shape[0], buf, sp))
+        ev = None if encoder_done is None else C.c_void_p(encoder_done.cuda_event)
+        _chk(lib().ita_vitlstm_front_ev(self._h, img.data_ptr(), dt, img.shape[0], buf, sp, ev))
         return img.shape[0]
 
     def back(self, desvel, quat, hidden, out, buf: int, stream=None):

@@ -113,6 +113,12 @@ int ita_vitlstm_forward(ita_handle h, const void* image_dev, int image_dtype, co
  * The caller orders them with events: back(t) after front(t); front(t+2) after back(t) (it reuses
  * buffer t%2).  front + back on one stream equals ita_vitlstm_forward.  Needs tail mode 1. */
 int ita_vitlstm_front(ita_handle h, const void* image_dev, int image_dtype, int batch, int buf, void* stream);
+/* the same, and records `encoder_done_event` (a hipEvent_t, may be NULL) on `stream` between the encoder and the
+ * folded GEMM.  The encoder kernel owns every CU (one persistent workgroup each, all of LDS and VGPRs): small
+ * kernels launched next to it only delay some of its workgroups.  Making back(t) wait for this event of front(t+1)
+ * puts the LSTM kernels of step t next to the GEMM of step t+1, which leaves room for them. */
+int ita_vitlstm_front_ev(ita_handle h, const void* image_dev, int image_dtype, int batch, int buf, void* stream,
+                         void* encoder_done_event);
 int ita_vitlstm_back(ita_handle h, const float* additional_data_dev, const float* quat_data_dev,
                      const float* hidden_in_h_dev, const float* hidden_in_c_dev, float* output_dev,
                      float* hidden_out_h_dev, float* hidden_out_c_dev, int batch, int buf, void* stream);
