@@ -44,18 +44,18 @@ STAGE_WORK = {   # stage: (ops per frame, bound, peak in Tera-op/s, arithmetic)
 
 # dominant-stage -> kernel whose PMC traffic (profiles/kernel_traffic.json, collected with
 # tools/profile_gpu.sh on this same command) is reported as roofline.traffic
-STAGE_KERNEL = {"encoder": "ita_encoder_kernel<true>", "tokenizer": "ita_tokenizer_kernel<64, false>",
+STAGE_KERNEL = {"encoder": "ita_encoder_kernel<1>", "tokenizer": "ita_tokenizer_kernel<64, false>",
                 "tail_decoder": "ita_gemm_f16x3_kernel<128, 128, 2, 4>", "lstm_fc": "ita_lstm_layer_kernel<4>"}
 # algorithmic HBM bytes per frame of each stage as it is cut here (inputs + outputs that cross a launch)
 STAGE_BYTES = {"tokenizer": 21600 + 128 * 64 * 4, "encoder": 128 * 64 * 4 + 2 * 128 * 64 * 2,
                "tail_decoder": 2 * 128 * 64 * 2 + 512 * 4, "lstm_fc": 2 * 3 * 128 * 4 * 2 + 12}
 
 
-def pmc_traffic(stage, frames):
+def pmc_traffic(kernel, frames):
     try:
         with open(os.path.join(REPO, "profiles", "kernel_traffic.json")) as f:
             t = json.load(f)
-        k = t["kernels"][STAGE_KERNEL[stage]]
+        k = t["kernels"][kernel]
         return int(k["hbm_bytes_per_launch"] * frames / 1024), t["source"]
     except Exception:
         return None, None
@@ -111,7 +111,7 @@ def main():
     ap.add_argument("--image-dtype", choices=["u8", "f32"], default="u8",
                     help="u8: the wire format of the reference host (ita_wire.h; float(pixel)/255.0f of main.cpp:168-169 "
                          "is done on the device, bit-identically, inside the fused tokenizer+encoder kernel); "
-                         "f32: the graph's own input type (separate tokenizer launch)")
+                         "f32: the graph's own input type (same fused kernel, 4x the frame bytes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--pipeline", action="store_true", help="two streams: step t's LSTM back (ita_vitlstm_back) runs "
@@ -235,8 +235,8 @@ def main():
     per = {k: v / max(n_all, 1) for k, v in stage_all.items()}
     per["tail_decoder"] = per.pop("tail") + per.pop("decoder")
     per["encoder"] = per.pop("mha") + per.pop("ffn")
-    # u8 frames: the tokenizer runs inside the encoder kernel (ita_encoder_kernel<true>), one stage
-    fused_tok = a.image_dtype == "u8" and not os.environ.get("ITA_SPLIT_TOKENIZER")
+    # the tokenizer runs inside the encoder kernel (ita_encoder_kernel<1> u8 frames, <2> f32 frames), one stage
+    fused_tok = not os.environ.get("ITA_SPLIT_TOKENIZER")
     if fused_tok:
         per["encoder"] += per.pop("tokenizer")
     dom = max(per, key=per.get)
@@ -265,10 +265,11 @@ def main():
         if nprof == 0:
             dom_ms = per[dom]
         achieved = ops * B / (max(dom_ms, 1e-9) * 1e-3) / 1e12
-        traffic, tsrc = pmc_traffic(dom, B)
         kname = STAGE_KERNEL.get(dom, dom)
         if dom == "encoder":
-            kname = "ita_encoder_kernel<true>" if fused_tok else "ita_encoder_kernel<false>"
+            kname = ("ita_encoder_kernel<1>" if a.image_dtype == "u8" else "ita_encoder_kernel<2>") if fused_tok \
+                else "ita_encoder_kernel<0>"
+        traffic, tsrc = pmc_traffic(kname, B)
         roof = {"kernel": kname, "stage": dom, "bound": bound, "achieved": round(achieved, 3),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 5), "traffic": traffic,
                 "traffic_source": tsrc, "algorithmic_hbm_bytes_per_launch": STAGE_BYTES.get(dom, 0) * B,
@@ -279,7 +280,7 @@ def main():
             # (conservative).  Mixed form: minimum time = int8 ops / int8 peak + executed f32 MFMA flops / f32 peak.
             tok_flops = 2 * 128 * 64 * 52 * B
             t_min = ops * B / (peak * 1e12) + tok_flops / (157.3e12)
-            roof["algorithmic_hbm_bytes_per_launch"] = (5400 + 2 * 128 * 64 * 2) * B   # u8 frame in, f16 hi/lo planes out
+            roof["algorithmic_hbm_bytes_per_launch"] = ((5400 if a.image_dtype == "u8" else 21600) + 2 * 128 * 64 * 2) * B   # frame in, f16 hi/lo planes out
             roof["note"] = ("kernel = tokenizer (f32 MFMA) + int8 MHA + int8 FFN + both LayerNorms of each frame; "
                             "achieved/frac count the int8 ops only")
             roof["mixed"] = {"f32_flops_per_launch": tok_flops, "f32_peak": 157.3, "min_time_ms": round(t_min * 1e3, 5),

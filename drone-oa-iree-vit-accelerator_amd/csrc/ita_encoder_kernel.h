@@ -44,7 +44,7 @@ struct ItaEncArgs {
   float* h0_dst;
   const int* slots;
   // fused tokenizer (ita_encoder_kernel<true>): u8 wire frames in, tokens never leave the CU
-  const uint8_t* img;    // (B,60,90) u8
+  const void* img;       // (B,60,90) u8 wire frames (TOK 1) or f32 frames (TOK 2)
   const float* tok_w;    // [53][64]: conv weights k-major (rows 0..48), rows 49..51 zero, row 52 = conv bias;
                          // channel c of an odd row k is stored at c ^ 16 (LDS bank spread for the MFMA B reads)
   const float *tok_lnw, *tok_lnb;
@@ -142,11 +142,11 @@ __device__ __forceinline__ i32x16 tile_wreg_x(const i32x4 (&wf)[KSTEPS], const i
   return acc;
 }
 
-// TOK: the layer's input is computed in place from u8 wire frames (OverlapPatchMerging, reference
+// TOK (0 none, 1 u8 wire frames, 2 f32 frames): the layer's input is computed in place from the frames (OverlapPatchMerging, reference
 // models/ITA/QAT/layers.py:39-45; same arithmetic and operation order as ita_tokenizer_kernel) instead of
 // being read from a.x: between two frames the workgroup tokenizes its next frame into the registers that
 // phase 0 quantises -- no token round trip through HBM and one kernel boundary less.
-template <bool TOK>
+template <int TOK>
 __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
   using L = ItaEncLds;
   constexpr int S = 128, E = 64, P = 192, F = 256, EC = 16;
@@ -222,12 +222,22 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
   } while (0)
   // ---- fused tokenizer (TOK): fetch = global loads of one frame + the conv weights into registers,
   // tokenize = those registers -> this thread's 16 channels of its token in xr.
-  i32x4 tk_px = {0, 0, 0, 0}, tk_w[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  constexpr int NPX = TOK == 2 ? 3 : 1;      // 16-byte pieces of a frame per thread: 338 (u8) or 1350 (f32) in all
+  i32x4 tk_px[NPX], tk_w[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   auto tok_fetch = [&](int fb) {
-    const uint8_t* src = a.img + (size_t)fb * 5400;
-    tk_px = (i32x4){0, 0, 0, 0};
-    if (tid < 337) tk_px = *(const i32x4*)(src + 16 * tid);
-    else if (tid == 337) { tk_px.x = *(const int*)(src + 5392); tk_px.y = *(const int*)(src + 5396); }
+    if constexpr (TOK == 2) {
+      const float* src = (const float*)a.img + (size_t)fb * 5400;
+#pragma unroll
+      for (int j = 0; j < NPX; ++j) {
+        tk_px[j] = (i32x4){0, 0, 0, 0};
+        if (tid + 512 * j < 1350) tk_px[j] = *(const i32x4*)(src + 4 * (tid + 512 * j));
+      }
+    } else {
+      const uint8_t* src = (const uint8_t*)a.img + (size_t)fb * 5400;
+      tk_px[0] = (i32x4){0, 0, 0, 0};
+      if (tid < 337) tk_px[0] = *(const i32x4*)(src + 16 * tid);
+      else if (tid == 337) { tk_px[0].x = *(const int*)(src + 5392); tk_px[0].y = *(const int*)(src + 5396); }
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
       if (tid + 512 * j < 53 * 16) tk_w[j] = *(const i32x4*)(a.tok_w + 4 * (tid + 512 * j));
@@ -255,14 +265,28 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
         img[row * 96 + col] = 0.0f;
       }
     }
-    // 16 consecutive pixels per thread; they span at most two image rows.  Chunk 337's eight pad bytes
-    // (code 0 -> 0.0f) land in the bottom border.
-    if (otid < 338) {
-      const int y = (16 * otid) / 90, x = 16 * otid - 90 * y, n0 = 90 - x;
-      float* dst = img + (y + 3) * 96 + x + 3;
+    if constexpr (TOK == 2) {
+      // four consecutive f32 pixels per piece; a piece spans at most two image rows
 #pragma unroll
-      for (int e = 0; e < 16; ++e)
-        dst[e + (e >= n0 ? 6 : 0)] = lut[((unsigned)tk_px[e >> 2] >> (8 * (e & 3))) & 0xffu];
+      for (int j = 0; j < NPX; ++j) {
+        const int p = otid + 512 * j;
+        if (p < 1350) {
+          const int y = (4 * p) / 90, x = 4 * p - 90 * y, n0 = 90 - x;
+          float* dst = img + (y + 3) * 96 + x + 3;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dst[e + (e >= n0 ? 6 : 0)] = __int_as_float(tk_px[j][e]);
+        }
+      }
+    } else {
+      // 16 consecutive pixels per thread; they span at most two image rows.  Chunk 337's eight pad bytes
+      // (code 0 -> 0.0f) land in the bottom border.
+      if (otid < 338) {
+        const int y = (16 * otid) / 90, x = 16 * otid - 90 * y, n0 = 90 - x;
+        float* dst = img + (y + 3) * 96 + x + 3;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          dst[e + (e >= n0 ? 6 : 0)] = lut[((unsigned)tk_px[0][e >> 2] >> (8 * (e & 3))) & 0xffu];
+      }
     }
   };
   auto tok_compute = [&](int fb) {

@@ -255,8 +255,8 @@ int launch_ffn(ita_context* c, int layer, const float* x, float* y, int B, bool 
 // whole encoder layer in one launch (E = 64)
 int launch_encoder(ita_context* c, int layer, const float* x, float* y, _Float16* y_hi, _Float16* y_lo, float* x1_tap,
                    int B, hipStream_t s, unsigned long long* stamps = nullptr, const float* h0_src = nullptr,
-                   float* h0_dst = nullptr, const int* slots = nullptr, const void* img_u8 = nullptr,
-                   float* tok_tap = nullptr) {
+                   float* h0_dst = nullptr, const int* slots = nullptr, const void* img = nullptr,
+                   float* tok_tap = nullptr, int img_dtype = ITA_IMAGE_U8) {
   const Layer& L = c->layers[layer];
   if (!L.n1w || !L.n2w) return fail(ITA_ERR_BAD_BLOB, "LayerNorm parameters missing from the blob");
   ItaEncArgs a{};
@@ -272,22 +272,24 @@ int launch_encoder(ita_context* c, int layer, const float* x, float* y, _Float16
   a.stamps = stamps;
   a.h0_src = h0_src; a.h0_dst = h0_dst; a.slots = slots;
   const int grid = B < c->num_cus ? B : c->num_cus;
-  if (img_u8) {   // tokenizer fused in front (u8 wire frames): x is not read
+  if (img) {   // tokenizer fused in front: x is not read
     if (!c->tok_w16 || !c->tok_lw || !c->tok_lb) return fail(ITA_ERR_BAD_BLOB, "tokenizer parameters missing from the blob");
-    a.img = (const uint8_t*)img_u8; a.tok_w = c->tok_w16; a.tok_lnw = c->tok_lw; a.tok_lnb = c->tok_lb; a.tok_tap = tok_tap;
-    hipLaunchKernelGGL(ita_encoder_kernel<true>, dim3(grid), dim3(512), ItaEncLds::TOTAL, s, a);
+    a.img = img; a.tok_w = c->tok_w16; a.tok_lnw = c->tok_lw; a.tok_lnb = c->tok_lb; a.tok_tap = tok_tap;
+    if (img_dtype == ITA_IMAGE_U8) hipLaunchKernelGGL(ita_encoder_kernel<1>, dim3(grid), dim3(512), ItaEncLds::TOTAL, s, a);
+    else hipLaunchKernelGGL(ita_encoder_kernel<2>, dim3(grid), dim3(512), ItaEncLds::TOTAL, s, a);
   } else {
-    hipLaunchKernelGGL(ita_encoder_kernel<false>, dim3(grid), dim3(512), ItaEncLds::TOTAL, s, a);
+    hipLaunchKernelGGL(ita_encoder_kernel<0>, dim3(grid), dim3(512), ItaEncLds::TOTAL, s, a);
   }
   HIPCHK(hipGetLastError());
   return ITA_OK;
 }
 
-// u8 wire frames into the E = 64 model: the tokenizer runs inside the first encoder layer's kernel
+// frames into the E = 64 model: the tokenizer runs inside the first encoder layer's kernel
 // (ITA_SPLIT_TOKENIZER=1 keeps the separate ita_tokenizer_kernel launch, for comparison)
 bool fuse_tokenizer(const ita_context* c, int image_dtype) {
   static const bool split = getenv("ITA_SPLIT_TOKENIZER") != nullptr;
-  return !split && image_dtype == ITA_IMAGE_U8 && c->hdr.E == 64 && c->tok_w16;
+  (void)image_dtype;
+  return !split && c->hdr.E == 64 && c->tok_w16;
 }
 
 int launch_tokenizer(ita_context* c, const void* img, int dtype, float* tokens, int B, hipStream_t s) {
@@ -498,8 +500,9 @@ int ita_create(ita_handle* out, int device_ordinal) {
   if ((rc = set_lds(ita_tokenizer_kernel<128, true>, ita_tok_lds_bytes<128>()))) { delete c; return rc; }
   if ((rc = set_lds(ita_tokenizer_kernel<128, false>, ita_tok_lds_bytes<128>()))) { delete c; return rc; }
   if ((rc = set_lds(ita_tail_kernel<64>, ita_tail_lds_bytes<64>()))) { delete c; return rc; }
-  if ((rc = set_lds(ita_encoder_kernel<false>, ItaEncLds::TOTAL))) { delete c; return rc; }
-  if ((rc = set_lds(ita_encoder_kernel<true>, ItaEncLds::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_encoder_kernel<0>, ItaEncLds::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_encoder_kernel<1>, ItaEncLds::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_encoder_kernel<2>, ItaEncLds::TOTAL))) { delete c; return rc; }
   {
     auto k1 = ita_gemm_f16x3_kernel<128, 128, 2, 4>;
     constexpr int b1 = ItaGemmSplitLds<128, 128>::TOTAL;
@@ -843,7 +846,7 @@ static int forward_impl(ita_handle h, const void* image, int image_dtype, const 
       if ((rc = launch_encoder(h, l, h->bufA, yout, planes ? h->x2_hi : nullptr, planes ? h->x2_lo : nullptr,
                                (taps && last) ? taps->x1 : nullptr, B, s, nullptr, (planes && stage_h0) ? h_in : nullptr,
                                (planes && stage_h0) ? h->gates : nullptr, slots, (fused_tok && l == 0) ? image : nullptr,
-                               (fused_tok && l == 0 && taps) ? taps->tokens : nullptr))) return rc;
+                               (fused_tok && l == 0 && taps) ? taps->tokens : nullptr, image_dtype))) return rc;
       MARK();
       MARK();
     } else {
@@ -953,7 +956,8 @@ static int front_impl(ita_handle h, const void* image, int image_dtype, int batc
   for (int l = 0; l < h->hdr.num_layers; ++l) {
     const bool last = l == h->hdr.num_layers - 1;
     if ((rc = launch_encoder(h, l, h->bufA, last ? nullptr : h->bufA, last ? h->x2_hi : nullptr, last ? h->x2_lo : nullptr,
-                             nullptr, batch, s, nullptr, nullptr, nullptr, nullptr, (fused_tok && l == 0) ? image : nullptr))) return rc;
+                             nullptr, batch, s, nullptr, nullptr, nullptr, nullptr, (fused_tok && l == 0) ? image : nullptr, nullptr,
+                             image_dtype))) return rc;
   }
   if ((rc = mark(1, true)) || (rc = mark(3, false))) return rc;
   if (encoder_done_event) HIPCHK(hipEventRecord((hipEvent_t)encoder_done_event, s));
