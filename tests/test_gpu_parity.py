@@ -275,6 +275,28 @@ def test_fused_tokenizer_path_equals_split_path(torch_cuda, oracle, B):
     eng.close()
 
 
+def test_refine_inputs_resize_and_default_quaternion(torch_cuda, oracle):
+    """refine_inputs (QAT/model.py:22-31): frames that are not 60 x 90 are resized bilinearly (align_corners=False) and a
+    missing quaternion is [1,0,0,0].  The resize runs through torch on the GPU; against the same resize done by torch
+    on the CPU (what the reference executes) the tokens agree to 1e-5 and the velocities to the tolerance the int8
+    path allows behind a float difference of that size (5e-4, as against the reference fixtures)."""
+    torch = torch_cuda
+    d = params.load_fixture(FIX_VIT[0])
+    eng, blob, fp = _engine(d, 64)
+    rs = np.random.RandomState(21)
+    big = rs.uniform(0, 1, size=(3, 1, 120, 180)).astype(np.float32)
+    dv = rs.uniform(2, 8, size=(3, 1)).astype(np.float32)
+    small = torch.nn.functional.interpolate(torch.from_numpy(big), size=(60, 90), mode="bilinear", align_corners=False)
+    model = host.ITAViTLSTM(blob, device=0)
+    v_big, _ = model([torch.from_numpy(big).cuda(), torch.from_numpy(dv).cuda()])          # no quaternion, no state
+    q = np.zeros((3, 4), np.float32); q[:, 0] = 1
+    ov, _, _, otp = oracle.forward(blob, small.numpy().reshape(3, 60, 90), dv, q, taps=True)
+    _, _, tpb = eng.forward(torch.from_numpy(big).cuda(), torch.from_numpy(dv).cuda(), taps=True)
+    np.testing.assert_allclose(tpb["tokens"].cpu().numpy(), otp["tokens"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(v_big.cpu().numpy(), ov, atol=5e-4, rtol=0)
+    eng.close()
+
+
 @pytest.mark.parametrize("dtype", ["f16", "f32"])
 def test_dropin_symbol_host_buffers(torch_cuda, oracle, dtype):
     """ITASelfAttention_workgroup(in, out) with the reference's prototype: host buffers of
