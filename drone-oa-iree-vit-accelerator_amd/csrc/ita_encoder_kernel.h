@@ -103,6 +103,21 @@ struct ItaWeightStage {
   }
 };
 
+// Requantise a 32x32 accumulator tile (rows = 32 features f0.., columns = 32 tokens t0..) and store it into a
+// chunk-major activation image.  Lane (r, h) holds, for token t0 + r, features f0 + 8g + 4h .. +3 (g = 0..3), i.e.
+// dwords of two different 16-byte slots; store_tile_fx writes them as four 4-byte stores that are 8-way bank
+// conflicted (64 lanes x 4 B at a 16-byte stride).  Two v_permlane32_swap give lane (r, 0) the whole slot of features
+// f0..f0+15 and lane (r, 1) the slot f0+16..f0+31: ONE conflict-free 16-byte store per lane.
+template <typename ACC>
+__device__ __forceinline__ void store_tile_cm16(const ACC& acc, float mult, float lo, char* dst, int f0, int t0, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  unsigned p4[4];
+  rq_pack16(acc, mult, lo, p4);
+  const auto s02 = __builtin_amdgcn_permlane32_swap(p4[0], p4[2], false, false);   // [0]: g0@h0 | g2@h0, [1]: g0@h1 | g2@h1
+  const auto s13 = __builtin_amdgcn_permlane32_swap(p4[1], p4[3], false, false);
+  *(i32x4*)(dst + cm_off(t0 + r, f0 + 16 * h, 128)) = (i32x4){(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
+}
+
 // 32x32 tile: A = weights from a chunk-major LDS image (WROWS rows), Bt = activations (128 rows)
 template <int KB, int WROWS>
 __device__ __forceinline__ i32x16 tile_wlds_x(const char* lds_w, int f0, const int* lds_bias, const char* lds_act,
@@ -418,8 +433,7 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
                                  tt * 32, lane);
       };
       auto qk_store = [&](const i32x16& acc, int mat, int dt) {
-        store_tile_fx<true>(acc, mat == 0 ? a.mq : a.mk, -128.0f, lds + (mat == 0 ? L::Q : L::K), 0, dt * 32, tt * 32,
-                            lane, nullptr, 0);
+        store_tile_cm16(acc, mat == 0 ? a.mq : a.mk, -128.0f, lds + (mat == 0 ? L::Q : L::K), dt * 32, tt * 32, lane);
       };
       auto v_acc = [&](int dt) {
         const int d = dt * 32 + r;
@@ -585,7 +599,7 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
     // ---------------- phase O: out_proj, weights in registers -> out_q (chunk-major, over x_q)
     {
       const i32x16 acc = tile_wreg_x<6>(wo_f, l_bo, et * 32, lds + L::Q, tt * 32, lane);
-      store_tile_fx<true>(acc, a.mo, -128.0f, lds + L::XQ, 0, et * 32, tt * 32, lane, nullptr, 0);
+      store_tile_cm16(acc, a.mo, -128.0f, lds + L::XQ, et * 32, tt * 32, lane);
     }
     lds_barrier();
     ITA_STAMP(4);
@@ -620,8 +634,8 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
     for (int ft = (wave >> 2) * 4; ft < (wave >> 2) * 4 + 4; ft += 2) {   // two tiles in flight, as in phase P
       const i32x16 a0 = tile_wlds_x<E, F>(lds + L::W1, ft * 32, l_b1, lds + L::XQ, tt * 32, lane);
       const i32x16 a1 = tile_wlds_x<E, F>(lds + L::W1, (ft + 1) * 32, l_b1, lds + L::XQ, tt * 32, lane);
-      store_tile_fx<true>(a0, a.m1, 0.0f, lds + L::H, 0, ft * 32, tt * 32, lane, nullptr, 0);
-      store_tile_fx<true>(a1, a.m1, 0.0f, lds + L::H, 0, (ft + 1) * 32, tt * 32, lane, nullptr, 0);
+      store_tile_cm16(a0, a.m1, 0.0f, lds + L::H, ft * 32, tt * 32, lane);
+      store_tile_cm16(a1, a.m1, 0.0f, lds + L::H, (ft + 1) * 32, tt * 32, lane);
     }
     lds_barrier();
     ITA_STAMP(6);
@@ -629,7 +643,7 @@ __global__ __launch_bounds__(512) void ita_encoder_kernel(const ItaEncArgs a) {
     // ---------------- phase F2: fc2 -> out_q (over the FFN's x_q)
     {
       const i32x16 acc = tile_wlds_x<F, E>(lds + L::W2, et * 32, l_b2, lds + L::H, tt * 32, lane);
-      store_tile_fx<true>(acc, a.m2, -128.0f, lds + L::XQ, 0, et * 32, tt * 32, lane, nullptr, 0);
+      store_tile_cm16(acc, a.m2, -128.0f, lds + L::XQ, et * 32, tt * 32, lane);
     }
     lds_barrier();
     ITA_STAMP(7);
