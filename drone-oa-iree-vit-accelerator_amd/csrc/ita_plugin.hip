@@ -19,6 +19,7 @@
 #include "ita_f16x3_kernels.h"
 #include "ita_f32_kernels.h"
 #include "ita_int8_kernels.h"
+#include "ita_stream_kernel.h"
 
 namespace {
 
@@ -49,6 +50,9 @@ struct Layer {
   const int32_t *bq, *bk, *bv, *bo, *b1, *b2;
   float ascal[ITA_A_NSCAL], fscal[ITA_F_NSCAL];
   const float *n1w, *n1b, *n2w, *n2b;
+  // LDS images of the stream kernels (ita_stream_kernel.h), device copies: whole layer, whole layer with the
+  // tokenizer in front (layer 0 of the E = 64 model), attention block only
+  char *simg_enc = nullptr, *simg_tok = nullptr, *simg_mha = nullptr;
 };
 
 }  // namespace
@@ -125,6 +129,13 @@ const T* hptr(ita_context* c, const char* name) {
 }
 
 void free_weights(ita_context* c) {
+  for (Layer& L : c->layers) {
+    char** im[] = {&L.simg_enc, &L.simg_tok, &L.simg_mha};
+    for (char** q : im) {
+      if (*q) (void)hipFree(*q);
+      *q = nullptr;
+    }
+  }
   if (c->dblob) (void)hipFree(c->dblob);
   if (c->tail_wT) (void)hipFree(c->tail_wT);
   if (c->tok_wT) (void)hipFree(c->tok_wT);
@@ -252,6 +263,114 @@ int launch_ffn(ita_context* c, int layer, const float* x, float* y, int B, bool 
   return ITA_OK;
 }
 
+
+// ---- stream kernels (ita_stream_kernel.h): the LDS image a workgroup copies verbatim at start-up.
+// Natural-k matrices (Wq, Wk, Wv, W1) are chunk-major [k/16][row][16].  The block output projections (Wo, fc2)
+// consume activations that were packed four 16-feature tiles at a time straight from MFMA accumulators:
+// fragment ks of lane (token, kq) holds, at byte 4j+i, feature 16(4ks+j) + 4kq + i -- so chunk 4ks+kq of their
+// image holds those input features, and image row 16et + rho is output channel (E/4)(rho>>2) + 4et + (rho&3),
+// which hands lane (token, kq) its own channels (E/4)kq + 4et + i.
+struct StreamHostParams {
+  const int8_t *wq, *wk, *wv, *wo, *w1, *w2;
+  const int32_t *bq, *bk, *bv, *bo, *b1, *b2;
+  const float *n1w, *n1b, *n2w, *n2b, *tlw, *tlb, *conv_w, *conv_b;
+};
+
+template <int E, bool FFN, bool TOK>
+int build_stream_image(const StreamHostParams& p, char** d_out) {
+  using L = ItaStreamLds<E, FFN, TOK>;
+  constexpr int P = 192, F = 256;
+  std::vector<char> im(L::IMAGE, 0);
+  auto natural = [&](int off, const int8_t* w, int rows, int kb) {
+    for (int r = 0; r < rows; ++r)
+      for (int k = 0; k < kb; ++k) im[off + (((k >> 4) * rows + r) << 4) + (k & 15)] = (char)w[(size_t)r * kb + k];
+  };
+  auto fragment = [&](int off, const int8_t* w, int nks, int kb) {   // w: [E][kb], kb = 64 * nks
+    for (int ks = 0; ks < nks; ++ks)
+      for (int kq = 0; kq < 4; ++kq)
+        for (int et = 0; et < E / 16; ++et)
+          for (int rho = 0; rho < 16; ++rho) {
+            const int ch = (E / 4) * (rho >> 2) + 4 * et + (rho & 3);
+            for (int j = 0; j < 4; ++j)
+              for (int i = 0; i < 4; ++i)
+                im[off + (((4 * ks + kq) * E + et * 16 + rho) << 4) + 4 * j + i] =
+                    (char)w[(size_t)ch * kb + (4 * ks + j) * 16 + 4 * kq + i];
+          }
+  };
+  natural(L::WQ, p.wq, P, E); natural(L::WK, p.wk, P, E); natural(L::WV, p.wv, P, E);
+  fragment(L::WO, p.wo, 3, P);
+  int32_t* bias = (int32_t*)(im.data() + L::BIAS);
+  memcpy(bias, p.bq, P * 4); memcpy(bias + P, p.bk, P * 4); memcpy(bias + 2 * P, p.bv, P * 4);
+  memcpy(bias + 3 * P, p.bo, E * 4);
+  float* ln = (float*)(im.data() + L::LNP);
+  if (p.n1w && p.n1b) { memcpy(ln, p.n1w, E * 4); memcpy(ln + E, p.n1b, E * 4); }
+  if constexpr (FFN) {
+    natural(L::W1, p.w1, F, E);
+    fragment(L::W2, p.w2, 4, F);
+    memcpy(bias + 3 * P + E, p.b1, F * 4); memcpy(bias + 3 * P + E + F, p.b2, E * 4);
+    memcpy(ln + 2 * E, p.n2w, E * 4); memcpy(ln + 3 * E, p.n2b, E * 4);
+  }
+  if constexpr (TOK) {
+    memcpy(ln + 4 * E, p.tlw, E * 4); memcpy(ln + 5 * E, p.tlb, E * 4);
+    // A fragments of v_mfma_f32_16x16x4_f32: lane (rho = lane & 15, k = lane >> 4) of step s, channel tile ct
+    float* cw = (float*)(im.data() + L::CW);
+    for (int s = 0; s < 13; ++s)
+      for (int ct = 0; ct < 4; ++ct)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int t = 4 * s + (lane >> 4), rho = lane & 15, ch = 16 * (rho >> 2) + 4 * ct + (rho & 3);
+          cw[(s * 4 + ct) * 64 + lane] = t < 49 ? p.conv_w[(size_t)ch * 49 + t] : 0.0f;
+        }
+    memcpy(im.data() + L::CB, p.conv_b, E * 4);
+  }
+  HIPCHK(hipMalloc(d_out, im.size()));
+  HIPCHK(hipMemcpy(*d_out, im.data(), im.size(), hipMemcpyHostToDevice));
+  return ITA_OK;
+}
+
+struct StreamIo {
+  const float* x = nullptr;
+  float* y = nullptr;
+  _Float16 *y_hi = nullptr, *y_lo = nullptr;
+  float* x1_tap = nullptr;
+  unsigned long long* stamps = nullptr;
+  const float* h0_src = nullptr;
+  float* h0_dst = nullptr;
+  const int* slots = nullptr;
+  const void* img = nullptr;   // u8 wire frames: tokenizer fused in front (x unused)
+  float* tok_tap = nullptr;
+};
+
+// mode 0: whole encoder layer; 1: attention block only (fuse_ln: + residual + LayerNorm1)
+int launch_stream(ita_context* c, int layer, int mode, bool fuse_ln, const StreamIo& io, int B, hipStream_t s) {
+  const Layer& L = c->layers[layer];
+  ItaStreamArgs a{};
+  a.x = io.x; a.y = io.y; a.y_hi = io.y_hi; a.y_lo = io.y_lo; a.ld_planes = LDFOLD; a.x1_tap = io.x1_tap;
+  a.inv_sx = L.ascal[ITA_A_INV_SX]; a.mq = L.ascal[ITA_A_MQ]; a.mk = L.ascal[ITA_A_MK]; a.mv = L.ascal[ITA_A_MV];
+  a.ml = L.ascal[ITA_A_ML]; a.mc = L.ascal[ITA_A_MC]; a.mo = L.ascal[ITA_A_MO]; a.so = L.ascal[ITA_A_SO];
+  a.f_inv_sx = L.fscal[ITA_F_INV_SX]; a.m1 = L.fscal[ITA_F_M1]; a.m2 = L.fscal[ITA_F_M2]; a.s2 = L.fscal[ITA_F_S2];
+  a.B = B; a.fuse_ln = fuse_ln ? 1 : 0;
+  a.stamps = io.stamps; a.h0_src = io.h0_src; a.h0_dst = io.h0_dst; a.slots = io.slots;
+  a.img = io.img; a.tok_tap = io.tok_tap;
+  const int grid = B < c->num_cus ? B : c->num_cus;
+  if (mode == 1) {
+    if (!L.simg_mha) return fail(ITA_ERR_BAD_BLOB, "attention image missing");
+    if (fuse_ln && !L.n1w) return fail(ITA_ERR_BAD_BLOB, "norm1 parameters missing from the blob");
+    a.image = L.simg_mha;
+    if (c->hdr.E == 64) hipLaunchKernelGGL((ita_stream_kernel<64, false, 0>), dim3(grid), dim3(512), (ItaStreamLds<64, false, false>::TOTAL), s, a);
+    else hipLaunchKernelGGL((ita_stream_kernel<128, false, 0>), dim3(grid), dim3(512), (ItaStreamLds<128, false, false>::TOTAL), s, a);
+  } else if (io.img) {
+    if (!L.simg_tok) return fail(ITA_ERR_BAD_BLOB, "tokenizer / LayerNorm parameters missing from the blob");
+    a.image = L.simg_tok;
+    hipLaunchKernelGGL((ita_stream_kernel<64, true, 1>), dim3(grid), dim3(512), (ItaStreamLds<64, true, true>::TOTAL), s, a);
+  } else {
+    if (!L.simg_enc) return fail(ITA_ERR_BAD_BLOB, "LayerNorm parameters missing from the blob");
+    a.image = L.simg_enc;
+    hipLaunchKernelGGL((ita_stream_kernel<64, true, 0>), dim3(grid), dim3(512), (ItaStreamLds<64, true, false>::TOTAL), s, a);
+  }
+  HIPCHK(hipGetLastError());
+  return ITA_OK;
+}
+
 // whole encoder layer in one launch (E = 64)
 int launch_encoder(ita_context* c, int layer, const float* x, float* y, _Float16* y_hi, _Float16* y_lo, float* x1_tap,
                    int B, hipStream_t s, unsigned long long* stamps = nullptr, const float* h0_src = nullptr,
@@ -259,6 +378,13 @@ int launch_encoder(ita_context* c, int layer, const float* x, float* y, _Float16
                    float* tok_tap = nullptr, int img_dtype = ITA_IMAGE_U8) {
   const Layer& L = c->layers[layer];
   if (!L.n1w || !L.n2w) return fail(ITA_ERR_BAD_BLOB, "LayerNorm parameters missing from the blob");
+  static const bool old_enc = getenv("ITA_OLD_ENCODER") != nullptr;   // A/B switch: the barrier-phased kernel of round 1
+  if (!old_enc && !(img && img_dtype != ITA_IMAGE_U8)) {
+    StreamIo io;
+    io.x = x; io.y = y; io.y_hi = y_hi; io.y_lo = y_lo; io.x1_tap = x1_tap; io.stamps = stamps;
+    io.h0_src = h0_src; io.h0_dst = h0_dst; io.slots = slots; io.img = img; io.tok_tap = tok_tap;
+    return launch_stream(c, layer, 0, false, io, B, s);
+  }
   ItaEncArgs a{};
   a.x = x; a.y = y; a.y_hi = y_hi; a.y_lo = y_lo; a.x1_tap = x1_tap;
   a.wq = L.wq; a.wk = L.wk; a.wv = L.wv; a.wo = L.wo; a.w1 = L.w1; a.w2 = L.w2;
@@ -288,8 +414,9 @@ int launch_encoder(ita_context* c, int layer, const float* x, float* y, _Float16
 // (ITA_SPLIT_TOKENIZER=1 keeps the separate ita_tokenizer_kernel launch, for comparison)
 bool fuse_tokenizer(const ita_context* c, int image_dtype) {
   static const bool split = getenv("ITA_SPLIT_TOKENIZER") != nullptr;
-  (void)image_dtype;
-  return !split && c->hdr.E == 64 && c->tok_w16;
+  static const bool old_enc = getenv("ITA_OLD_ENCODER") != nullptr;
+  // f32 frames go through the stand-alone tokenizer: the stream kernel's private pixel windows are sized for bytes
+  return !split && c->hdr.E == 64 && c->tok_w16 && (old_enc || image_dtype == ITA_IMAGE_U8);
 }
 
 int launch_tokenizer(ita_context* c, const void* img, int dtype, float* tokens, int B, hipStream_t s) {
@@ -503,6 +630,10 @@ int ita_create(ita_handle* out, int device_ordinal) {
   if ((rc = set_lds(ita_encoder_kernel<0>, ItaEncLds::TOTAL))) { delete c; return rc; }
   if ((rc = set_lds(ita_encoder_kernel<1>, ItaEncLds::TOTAL))) { delete c; return rc; }
   if ((rc = set_lds(ita_encoder_kernel<2>, ItaEncLds::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_stream_kernel<64, true, 1>, ItaStreamLds<64, true, true>::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_stream_kernel<64, true, 0>, ItaStreamLds<64, true, false>::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_stream_kernel<64, false, 0>, ItaStreamLds<64, false, false>::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_stream_kernel<128, false, 0>, ItaStreamLds<128, false, false>::TOTAL))) { delete c; return rc; }
   {
     auto k1 = ita_gemm_f16x3_kernel<128, 128, 2, 4>;
     constexpr int b1 = ItaGemmSplitLds<128, 128>::TOTAL;
@@ -591,6 +722,30 @@ int ita_load_weights(ita_handle h, const void* blob, size_t nbytes) {
   h->tail_b = dptr<float>(h, "tail.conv_b", false, &ok);
   h->dec_w = dptr<float>(h, "dec.w", false, &ok); h->dec_b = dptr<float>(h, "dec.b", false, &ok);
   h->fc_w = dptr<float>(h, "fc.w", false, &ok); h->fc_b = dptr<float>(h, "fc.b", false, &ok);
+  for (int i = 0; i < hdr.num_layers; ++i) {
+    Layer& L = h->layers[i];
+    StreamHostParams sp{};
+#define NM(fmt) (snprintf(nm, sizeof nm, fmt, i), nm)
+    sp.wq = hptr<int8_t>(h, NM("attn%d.wq")); sp.wk = hptr<int8_t>(h, NM("attn%d.wk")); sp.wv = hptr<int8_t>(h, NM("attn%d.wv"));
+    sp.wo = hptr<int8_t>(h, NM("attn%d.wo")); sp.w1 = hptr<int8_t>(h, NM("ffn%d.w1")); sp.w2 = hptr<int8_t>(h, NM("ffn%d.w2"));
+    sp.bq = hptr<int32_t>(h, NM("attn%d.bq")); sp.bk = hptr<int32_t>(h, NM("attn%d.bk")); sp.bv = hptr<int32_t>(h, NM("attn%d.bv"));
+    sp.bo = hptr<int32_t>(h, NM("attn%d.bo")); sp.b1 = hptr<int32_t>(h, NM("ffn%d.b1")); sp.b2 = hptr<int32_t>(h, NM("ffn%d.b2"));
+    sp.n1w = hptr<float>(h, NM("norm1_%d.w")); sp.n1b = hptr<float>(h, NM("norm1_%d.b"));
+    sp.n2w = hptr<float>(h, NM("norm2_%d.w")); sp.n2b = hptr<float>(h, NM("norm2_%d.b"));
+#undef NM
+    sp.tlw = hptr<float>(h, "tok.ln_w"); sp.tlb = hptr<float>(h, "tok.ln_b");
+    sp.conv_w = hptr<float>(h, "tok.conv_w"); sp.conv_b = hptr<float>(h, "tok.conv_b");
+    int rc2 = ITA_OK;
+    const bool lns = sp.n1w && sp.n1b && sp.n2w && sp.n2b;
+    if (hdr.E == 64) {
+      rc2 = build_stream_image<64, false, false>(sp, &L.simg_mha);
+      if (!rc2 && lns) rc2 = build_stream_image<64, true, false>(sp, &L.simg_enc);
+      if (!rc2 && lns && i == 0 && sp.tlw && sp.tlb && sp.conv_w && sp.conv_b) rc2 = build_stream_image<64, true, true>(sp, &L.simg_tok);
+    } else {
+      rc2 = build_stream_image<128, false, false>(sp, &L.simg_mha);
+    }
+    if (rc2) { free_weights(h); return rc2; }
+  }
   if (const float* cw = hptr<float>(h, "tok.conv_w")) {
     const int Ei = hdr.E;
     std::vector<float> wT((size_t)50 * Ei, 0.0f);

@@ -294,8 +294,8 @@ class Engine:
         return vel, (h_out, c_out)
 
     def encoder_stamps(self, x, layer: int = 0):
-        """diagnostic: per-phase s_memtime stamps of the fused encoder kernel -> int64 [blocks, 8, 16].
-        x: (B,128,64) f32 tokens, or (B,60,90) u8 frames (tokenizer fused in front; slots 9..12)"""
+        """diagnostic: per-phase s_memtime stamps of the encoder stream kernel -> int64 [blocks, 8 frames, 2 waves
+        (0 and 4), 16 slots].  x: (B,128,64) f32 tokens, or (B,60,90) u8 frames (tokenizer fused in front; slots 9, 10)"""
         torch = _torch()
         B = x.shape[0]
         if x.dtype == torch.uint8:
@@ -304,7 +304,7 @@ class Engine:
             img, xp = None, _dev_f32(x)
         y = torch.empty((B, 128, self.E), dtype=torch.float32, device=x.device)
         nb = min(B, torch.cuda.get_device_properties(x.device).multi_processor_count)
-        st = torch.zeros((nb, 8, 16), dtype=torch.int64, device=x.device)
+        st = torch.zeros((nb, 8, 2, 16), dtype=torch.int64, device=x.device)
         _chk(lib().ita_debug_encoder_stamps(self._h, layer, xp.data_ptr() if xp is not None else None,
                                             img.data_ptr() if img is not None else None, y.data_ptr(), B, st.data_ptr(),
                                             _stream_ptr()))

@@ -168,12 +168,12 @@ int ita_fusion_tail_load(ita_handle h, const float* conv_w_host, const float* co
 int ita_fusion_tail_large(ita_handle h, const float* x_dev, float* out_dev, int batch, int tok_h, int tok_w,
                           void* stream);
 
-/* Diagnostic: one encoder layer with in-kernel s_memtime stamps (wave 0 of every workgroup, its
- * first 8 frames, 16 slots): stamps[(block * 8 + frame) * 16 + slot], u64 device buffer of
- * min(batch, #CUs) * 128 entries.  Slots 0..8: the phase boundaries of the frame; with image_u8_dev
- * (tokenizer fused in front, x_dev unused) slots 9..12: the steps of tokenizing the NEXT frame; slots 13, 14:
- * arrival of waves 0 and 4 at the barrier that ends the projection phase.
- * Not used by the product path. */
+/* Diagnostic: one encoder layer (E = 64) with in-kernel s_memtime stamps, taken by waves 0 and 4 of every
+ * workgroup over its first 8 frames, 16 slots each: stamps[((block * 8 + frame) * 2 + wave / 4) * 16 + slot],
+ * a u64 device buffer of min(batch, #CUs) * 256 entries.  Slots: 0 frame start, 1 projections done, 2 past the
+ * K/V^T barrier, 3 logits, 4 softmax, 5 A.V, 6 past the second barrier, 7 out_proj + LayerNorm1, 8 fc1,
+ * 11 fc2 + LayerNorm2 + store; with image_u8_dev (tokenizer fused in front, x_dev unused) 9 and 10: patch blend
+ * and conv + LayerNorm of the NEXT frame.  Not used by the product path. */
 int ita_debug_encoder_stamps(ita_handle h, int layer, const float* x_dev, const void* image_u8_dev, float* y_dev,
                              int batch, unsigned long long* stamps_dev, void* stream);
 

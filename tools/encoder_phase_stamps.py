@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic (GPU box): where does a frame spend its cycles inside ita_encoder_kernel?
-Prints the median s_memtime delta per phase over all workgroups (frames 1..3 of each)."""
+"""Diagnostic (GPU box): where does a frame spend its cycles inside ita_stream_kernel?
+Prints the median s_memtime delta per phase (waves 0 and 4) over all workgroups (frames 1..3 of each)."""
 import os, sys
 import numpy as np
 import torch
@@ -15,22 +15,19 @@ x = torch.from_numpy(synth.frames(0, B)["img_u8"]).cuda() if fused else torch.ra
 for _ in range(3):
     st = eng.encoder_stamps(x)
 torch.cuda.synchronize()
-st = st.cpu().numpy().astype(np.int64)
-names = ["quant", "P(qkv proj)", "A(attn)", "O(out_proj)", "L1(ln1+quant)", "F1(fc1)", "F2(fc2)", "L2(ln2+store)"]
-frames = st[:, 1:4, :]                       # steady-state frames
-dt = np.diff(frames[..., :9], axis=-1)       # 8 phases
-print("s_memtime ticks (100 MHz constant clock? -> see total) per phase, median over WGs x frames")
-for i, n in enumerate(names):
-    print(f"  {n:16s} median {np.median(dt[..., i]):9.0f}  p90 {np.percentile(dt[..., i], 90):9.0f}")
-tot = frames[..., 8] - frames[..., 0]
-print(f"  frame total      median {np.median(tot):9.0f}")
-w0, w4 = frames[..., 13] - frames[..., 1], frames[..., 14] - frames[..., 1]
-# the two waves share a SIMD: what counts is their sum (the phase is VALU-issue bound), not their balance
-print(f"  phase P work: wave 0 (11 Q/K tiles) median {np.median(w0):7.0f}, wave 4 (1 K + 6 V tiles) median {np.median(w4):7.0f}")
-if fused:
-    tk = frames[..., [8, 9, 10, 11, 12]]
-    for i, n in enumerate(["T0+T1 image/weights -> LDS", "T2 blend", "T3 MFMA", "T4 LayerNorm"]):
-        d = tk[..., i + 1] - tk[..., i]
-        print(f"  tok {n:27s} median {np.median(d):9.0f}  p90 {np.percentile(d, 90):9.0f}")
-whole = st[:, 3, 8] - st[:, 0, 0]
-print(f"  4 frames (wg)    median {np.median(whole):9.0f}; first-frame start spread {st[:, 0, 0].max() - st[:, 0, 0].min()}")
+st = st.cpu().numpy().astype(np.int64)      # [blocks, 8, 2, 16]
+# slots: 0 frame start | 1 projections done (before B1) | 2 after B1 | 3 logits | 4 softmax | 5 AV (before B2) | 6 after B2
+#        | 7 out_proj + LN1 | 8 fc1 | 11 fc2 + LN2 + store | 9 tokenizer blend | 10 tokenizer MFMA + LN
+seq = [0, 1, 2, 3, 4, 5, 6, 7, 8, 11] + ([9, 10] if fused else [])
+names = ["quant + Q/K/V proj", "wait B1", "logits", "softmax", "AV", "wait B2", "out_proj + LN1", "fc1", "fc2 + LN2 + store"] + \
+        (["tok blend", "tok MFMA + LN"] if fused else [])
+for wv in (0, 1):
+    fr = st[:, 1:4, wv, :]
+    print(f"wave {4 * wv}: s_memtime ticks per phase, median / p90 over WGs x frames")
+    for i, n in enumerate(names):
+        dt = fr[..., seq[i + 1]] - fr[..., seq[i]]
+        print(f"  {n:20s} {np.median(dt):9.0f} {np.percentile(dt, 90):9.0f}")
+    nxt = st[:, 2:5, wv, 0] - st[:, 1:4, wv, 0]
+    print(f"  frame period         {np.median(nxt):9.0f} {np.percentile(nxt, 90):9.0f}")
+whole = st[:, 3, 0, 11] - st[:, 0, 0, 0]
+print(f"4 frames (wg) median {np.median(whole):9.0f}; first-frame start spread {st[:, 0, 0, 0].max() - st[:, 0, 0, 0].min()}")
