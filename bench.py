@@ -33,7 +33,7 @@ import numpy as np  # noqa: E402
 # algorithmic work per frame (BASELINE.md section 2 / SURVEY.md section 8(d)); E=64, S=128, P=192, F=256
 STAGE_WORK = {   # stage: (ops per frame, bound, peak in Tera-op/s, arithmetic)
     "tokenizer": (2 * 4.23e6, "mfma", 157.3, "f32"),
-    # int8 MHA + int8 FFN (+ both LayerNorms) are ONE launch: ita_encoder_kernel
+    # int8 MHA + int8 FFN (+ both LayerNorms) are ONE launch: ita_stream_kernel
     "encoder": (2 * (12.58e6 + 4.19e6), "mfma", 5000.0, "int8"),
     # fusion conv + decoder run as ONE folded GEMM on split-precision f16 MFMA (priced against the
     # dense f16 peak with the reference graph's algorithmic flops, not the 3x split products)
@@ -44,7 +44,7 @@ STAGE_WORK = {   # stage: (ops per frame, bound, peak in Tera-op/s, arithmetic)
 
 # dominant-stage -> kernel whose PMC traffic (profiles/kernel_traffic.json, collected with
 # tools/profile_gpu.sh on this same command) is reported as roofline.traffic
-STAGE_KERNEL = {"encoder": "ita_encoder_kernel<1>", "tokenizer": "ita_tokenizer_kernel<64, false>",
+STAGE_KERNEL = {"encoder": "ita_stream_kernel<64, true, 1, false>", "tokenizer": "ita_tokenizer_kernel<64, false>",
                 "tail_decoder": "ita_gemm_f16x3_kernel<128, 128, 2, 4>", "lstm_fc": "ita_lstm_layer_kernel<4>"}
 # algorithmic HBM bytes per frame of each stage as it is cut here (inputs + outputs that cross a launch)
 STAGE_BYTES = {"tokenizer": 21600 + 128 * 64 * 4, "encoder": 128 * 64 * 4 + 2 * 128 * 64 * 2,
@@ -235,8 +235,9 @@ def main():
     per = {k: v / max(n_all, 1) for k, v in stage_all.items()}
     per["tail_decoder"] = per.pop("tail") + per.pop("decoder")
     per["encoder"] = per.pop("mha") + per.pop("ffn")
-    # the tokenizer runs inside the encoder kernel (ita_encoder_kernel<1> u8 frames, <2> f32 frames), one stage
-    fused_tok = not os.environ.get("ITA_SPLIT_TOKENIZER")
+    # u8 wire frames: the tokenizer runs inside the encoder kernel (ita_stream_kernel<64, true, 1>), one stage;
+    # f32 frames go through the stand-alone tokenizer launch
+    fused_tok = not os.environ.get("ITA_SPLIT_TOKENIZER") and a.image_dtype == "u8"
     if fused_tok:
         per["encoder"] += per.pop("tokenizer")
     dom = max(per, key=per.get)
@@ -267,8 +268,7 @@ def main():
         achieved = ops * B / (max(dom_ms, 1e-9) * 1e-3) / 1e12
         kname = STAGE_KERNEL.get(dom, dom)
         if dom == "encoder":
-            kname = ("ita_encoder_kernel<1>" if a.image_dtype == "u8" else "ita_encoder_kernel<2>") if fused_tok \
-                else "ita_encoder_kernel<0>"
+            kname = "ita_stream_kernel<64, true, 1, false>" if fused_tok else "ita_stream_kernel<64, true, 0, false>"
         traffic, tsrc = pmc_traffic(kname, B)
         roof = {"kernel": kname, "stage": dom, "bound": bound, "achieved": round(achieved, 3),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 5), "traffic": traffic,

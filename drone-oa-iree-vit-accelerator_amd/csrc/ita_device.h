@@ -90,6 +90,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // scale step is written on float2 values.
 template <int N, typename ACC>
 __device__ __forceinline__ void scale_clamp(const ACC& acc, float mult, float lo, float (&f)[N]) {
+#ifdef ITA_SCALAR_SCALE
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    float v = (float)acc[i];
+    asm("v_mul_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(mult));   // asm: keeps the SLP vectoriser from re-packing it
+    f[i] = __builtin_amdgcn_fmed3f(v, lo, 127.0f);
+  }
+#else
   const f32x2 m2 = {mult, mult};
 #pragma unroll
   for (int i = 0; i < N; i += 2) {
@@ -97,6 +105,240 @@ __device__ __forceinline__ void scale_clamp(const ACC& acc, float mult, float lo
     v = v * m2;
     f[i] = __builtin_amdgcn_fmed3f(v.x, lo, 127.0f);
     f[i + 1] = __builtin_amdgcn_fmed3f(v.y, lo, 127.0f);
+  }
+#endif
+}
+// The same for accumulators that were started at ITA_ACC_BIAS (+ bias) instead of (bias): while |sum| < 2^22 the
+// int32 bit pattern 0x4B400000 + sum IS the float 1.5 * 2^23 + sum, so the int -> float conversion becomes an exact
+// float subtraction.  On gfx950 v_sub_f32 / v_mul_f32 issue at twice the rate of v_cvt_f32_i32 / v_pk_mul_f32 when two
+// waves share a SIMD (tools/microbench/valu_ops.hip).
+#define ITA_ACC_BIAS 0x4B400000
+template <int N, typename ACC>
+__device__ __forceinline__ void scale_clamp_b(const ACC& acc, float mult, float lo, float (&f)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const float x = __int_as_float(acc[i]) - ITA_MAGIC_F;
+    f[i] = __builtin_amdgcn_fmed3f(x * mult, lo, 127.0f);
+  }
+}
+// ---- fixed-schedule requantisation of biased accumulators (ITA_ACC_BIAS).  What limits the encoder kernel is the
+// NUMBER of VALU instructions a SIMD issues (measured: 4.0 cycles of SQ_ACTIVE_INST_VALU per instruction whatever its
+// class, two waves per SIMD), so the steps that exist in packed form run packed -- v_pk_add_f32 / v_pk_mul_f32 handle two
+// values per instruction -- and every block is one asm statement in an order where consecutive instructions never depend
+// on each other (left to itself hipcc funnels all values through one temporary, and a dependent VALU instruction
+// issues ~1.7x slower).  mult / lo / scale must be wave-uniform.
+// Hazard: hipcc pads MFMA -> VALU read wait states for its own instructions, not for inline asm; an accumulator may come
+// from a 4-pass MFMA issued immediately before (7-8 wait states on gfx950), so the first block opens with ten.
+template <int NP>   // NP register pairs: x = (x - 1.5 * 2^23) * mult
+__device__ __forceinline__ void pk_unbias_scale(f32x2 (&x)[NP], float mult) {
+  static_assert(NP == 8 || NP == 4, "");
+  const f32x2 c2 = {-ITA_MAGIC_F, -ITA_MAGIC_F}, m2 = {mult, mult};
+  if constexpr (NP == 8) {
+    asm("s_nop 7\n\ts_nop 1\n\t"
+      "v_pk_add_f32 %0, %0, %8\n\t"
+      "v_pk_add_f32 %1, %1, %8\n\t"
+      "v_pk_add_f32 %2, %2, %8\n\t"
+      "v_pk_add_f32 %3, %3, %8\n\t"
+      "v_pk_add_f32 %4, %4, %8\n\t"
+      "v_pk_add_f32 %5, %5, %8\n\t"
+      "v_pk_add_f32 %6, %6, %8\n\t"
+      "v_pk_add_f32 %7, %7, %8\n\t"
+      "v_pk_mul_f32 %0, %0, %9\n\t"
+      "v_pk_mul_f32 %1, %1, %9\n\t"
+      "v_pk_mul_f32 %2, %2, %9\n\t"
+      "v_pk_mul_f32 %3, %3, %9\n\t"
+      "v_pk_mul_f32 %4, %4, %9\n\t"
+      "v_pk_mul_f32 %5, %5, %9\n\t"
+      "v_pk_mul_f32 %6, %6, %9\n\t"
+      "v_pk_mul_f32 %7, %7, %9"
+        : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])
+        : "s"(c2), "s"(m2));
+  } else {
+    asm("s_nop 7\n\ts_nop 1\n\t"
+      "v_pk_add_f32 %0, %0, %4\n\t"
+      "v_pk_add_f32 %1, %1, %4\n\t"
+      "v_pk_add_f32 %2, %2, %4\n\t"
+      "v_pk_add_f32 %3, %3, %4\n\t"
+      "v_pk_mul_f32 %0, %0, %5\n\t"
+      "v_pk_mul_f32 %1, %1, %5\n\t"
+      "v_pk_mul_f32 %2, %2, %5\n\t"
+      "v_pk_mul_f32 %3, %3, %5"
+        : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])
+        : "s"(c2), "s"(m2));
+  }
+}
+// clamp sixteen floats, round them to nearest-even integers and pack their low bytes: pk[g] byte b = rne(clamp(f[4g+b]))
+__device__ __forceinline__ i32x4 clamp_round_pack16(float (&f)[16], float lo) {
+  unsigned p0, p1, p2, p3;
+  const float hi = 127.0f, mg = ITA_MAGIC_F;
+  asm(
+      "v_med3_f32 %4, %4, %20, %21\n\t"
+      "v_med3_f32 %5, %5, %20, %21\n\t"
+      "v_med3_f32 %6, %6, %20, %21\n\t"
+      "v_med3_f32 %7, %7, %20, %21\n\t"
+      "v_med3_f32 %8, %8, %20, %21\n\t"
+      "v_med3_f32 %9, %9, %20, %21\n\t"
+      "v_med3_f32 %10, %10, %20, %21\n\t"
+      "v_med3_f32 %11, %11, %20, %21\n\t"
+      "v_med3_f32 %12, %12, %20, %21\n\t"
+      "v_med3_f32 %13, %13, %20, %21\n\t"
+      "v_med3_f32 %14, %14, %20, %21\n\t"
+      "v_med3_f32 %15, %15, %20, %21\n\t"
+      "v_med3_f32 %16, %16, %20, %21\n\t"
+      "v_med3_f32 %17, %17, %20, %21\n\t"
+      "v_med3_f32 %18, %18, %20, %21\n\t"
+      "v_med3_f32 %19, %19, %20, %21\n\t"
+      "v_add_f32_sdwa %0, %4, %22 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %1, %8, %22 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %2, %12, %22 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %3, %16, %22 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %0, %5, %22 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %1, %9, %22 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %2, %13, %22 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %3, %17, %22 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %0, %6, %22 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %1, %10, %22 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %2, %14, %22 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %3, %18, %22 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %0, %7, %22 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %1, %11, %22 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %2, %15, %22 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_add_f32_sdwa %3, %19, %22 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "s_nop 0"
+      : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]),
+        "+v"(f[6]), "+v"(f[7]), "+v"(f[8]), "+v"(f[9]), "+v"(f[10]), "+v"(f[11]), "+v"(f[12]), "+v"(f[13]), "+v"(f[14]),
+        "+v"(f[15])
+      : "s"(lo), "v"(hi), "v"(mg));
+  return (i32x4){(int)p0, (int)p1, (int)p2, (int)p3};
+}
+// the same arithmetic left to the compiler's scheduler (it interleaves the VALU work with the MFMAs and LDS reads
+// around it; only the byte-insert block is fixed): experiment switch ITA_RQ_STYLE=1
+__device__ __forceinline__ i32x4 rq_pack16_c(const i32x4 (&acc)[4], float mult, float lo) {
+  const f32x2 c2 = {-ITA_MAGIC_F, -ITA_MAGIC_F}, m2 = {mult, mult};
+  float f[16];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    f32x2 v = {__int_as_float(acc[k >> 1][2 * (k & 1)]), __int_as_float(acc[k >> 1][2 * (k & 1) + 1])};
+    v = (v + c2) * m2;
+    f[2 * k] = __builtin_amdgcn_fmed3f(v.x, lo, 127.0f);
+    f[2 * k + 1] = __builtin_amdgcn_fmed3f(v.y, lo, 127.0f);
+  }
+  unsigned p4[4];
+  round_pack16(f, p4);
+  return (i32x4){(int)p4[0], (int)p4[1], (int)p4[2], (int)p4[3]};
+}
+__device__ __forceinline__ void dq16_c(const i32x4 (&acc)[4], float mult, float scale, float (&d)[16]) {
+  const f32x2 c2 = {-ITA_MAGIC_F, -ITA_MAGIC_F}, m2 = {mult, mult}, s2 = {scale, scale};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    f32x2 v = {__int_as_float(acc[k >> 1][2 * (k & 1)]), __int_as_float(acc[k >> 1][2 * (k & 1) + 1])};
+    v = (v + c2) * m2;
+    f32x2 r = {__builtin_rintf(__builtin_amdgcn_fmed3f(v.x, -128.0f, 127.0f)), __builtin_rintf(__builtin_amdgcn_fmed3f(v.y, -128.0f, 127.0f))};
+    r = r * s2;
+    d[2 * k] = r.x; d[2 * k + 1] = r.y;
+  }
+}
+__device__ __forceinline__ void lg8_c(const i32x4 (&acc)[2], float mult, unsigned (&bits)[8]) {
+  const f32x2 c2 = {-ITA_MAGIC_F, -ITA_MAGIC_F}, m2 = {mult, mult}, mg2 = {ITA_MAGIC_F, ITA_MAGIC_F};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    f32x2 v = {__int_as_float(acc[k >> 1][2 * (k & 1)]), __int_as_float(acc[k >> 1][2 * (k & 1) + 1])};
+    v = (v + c2) * m2;
+    f32x2 r = {__builtin_amdgcn_fmed3f(v.x, -128.0f, 127.0f), __builtin_amdgcn_fmed3f(v.y, -128.0f, 127.0f)};
+    r = r + mg2;
+    bits[2 * k] = __float_as_uint(r.x); bits[2 * k + 1] = __float_as_uint(r.y);
+  }
+}
+// requantise + pack sixteen biased accumulators (four 16x16 tiles): 8 + 8 + 16 + 16 VALU instructions
+__device__ __forceinline__ i32x4 rq_pack16_b(const i32x4 (&acc)[4], float mult, float lo) {
+  f32x2 x[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x[k] = (f32x2){__int_as_float(acc[k >> 1][2 * (k & 1)]), __int_as_float(acc[k >> 1][2 * (k & 1) + 1])};
+  pk_unbias_scale<8>(x, mult);
+  float f[16];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { f[2 * k] = x[k].x; f[2 * k + 1] = x[k].y; }
+  return clamp_round_pack16(f, lo);
+}
+// block output: d[4t+i] = float(int8 code) * scale for sixteen biased accumulators: 8 + 8 + 16 + 16 + 8
+__device__ __forceinline__ void dq16_b(const i32x4 (&acc)[4], float mult, float scale, float (&d)[16]) {
+  f32x2 x[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x[k] = (f32x2){__int_as_float(acc[k >> 1][2 * (k & 1)]), __int_as_float(acc[k >> 1][2 * (k & 1) + 1])};
+  pk_unbias_scale<8>(x, mult);
+  float f[16];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { f[2 * k] = x[k].x; f[2 * k + 1] = x[k].y; }
+  const float lo = -128.0f, hi = 127.0f;
+  asm(
+      "v_med3_f32 %0, %0, %16, %17\n\t"
+      "v_med3_f32 %1, %1, %16, %17\n\t"
+      "v_med3_f32 %2, %2, %16, %17\n\t"
+      "v_med3_f32 %3, %3, %16, %17\n\t"
+      "v_med3_f32 %4, %4, %16, %17\n\t"
+      "v_med3_f32 %5, %5, %16, %17\n\t"
+      "v_med3_f32 %6, %6, %16, %17\n\t"
+      "v_med3_f32 %7, %7, %16, %17\n\t"
+      "v_med3_f32 %8, %8, %16, %17\n\t"
+      "v_med3_f32 %9, %9, %16, %17\n\t"
+      "v_med3_f32 %10, %10, %16, %17\n\t"
+      "v_med3_f32 %11, %11, %16, %17\n\t"
+      "v_med3_f32 %12, %12, %16, %17\n\t"
+      "v_med3_f32 %13, %13, %16, %17\n\t"
+      "v_med3_f32 %14, %14, %16, %17\n\t"
+      "v_med3_f32 %15, %15, %16, %17\n\t"
+      "v_rndne_f32 %0, %0\n\t"
+      "v_rndne_f32 %1, %1\n\t"
+      "v_rndne_f32 %2, %2\n\t"
+      "v_rndne_f32 %3, %3\n\t"
+      "v_rndne_f32 %4, %4\n\t"
+      "v_rndne_f32 %5, %5\n\t"
+      "v_rndne_f32 %6, %6\n\t"
+      "v_rndne_f32 %7, %7\n\t"
+      "v_rndne_f32 %8, %8\n\t"
+      "v_rndne_f32 %9, %9\n\t"
+      "v_rndne_f32 %10, %10\n\t"
+      "v_rndne_f32 %11, %11\n\t"
+      "v_rndne_f32 %12, %12\n\t"
+      "v_rndne_f32 %13, %13\n\t"
+      "v_rndne_f32 %14, %14\n\t"
+      "v_rndne_f32 %15, %15"
+      : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]), "+v"(f[9]),
+        "+v"(f[10]), "+v"(f[11]), "+v"(f[12]), "+v"(f[13]), "+v"(f[14]), "+v"(f[15])
+      : "s"(lo), "v"(hi));
+  const f32x2 s2 = {scale, scale};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const f32x2 v = (f32x2){f[2 * k], f[2 * k + 1]} * s2;
+    d[2 * k] = v.x; d[2 * k + 1] = v.y;
+  }
+}
+// logits: eight biased accumulators (two key tiles) -> float bit patterns whose low 16 bits hold rne(clamp(acc * mult))
+__device__ __forceinline__ void lg8_b(const i32x4 (&acc)[2], float mult, unsigned (&bits)[8]) {
+  f32x2 x[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) x[k] = (f32x2){__int_as_float(acc[k >> 1][2 * (k & 1)]), __int_as_float(acc[k >> 1][2 * (k & 1) + 1])};
+  pk_unbias_scale<4>(x, mult);
+  float f[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { f[2 * k] = x[k].x; f[2 * k + 1] = x[k].y; }
+  const float lo = -128.0f, hi = 127.0f;
+  asm(
+      "v_med3_f32 %0, %0, %8, %9\n\t"
+      "v_med3_f32 %1, %1, %8, %9\n\t"
+      "v_med3_f32 %2, %2, %8, %9\n\t"
+      "v_med3_f32 %3, %3, %8, %9\n\t"
+      "v_med3_f32 %4, %4, %8, %9\n\t"
+      "v_med3_f32 %5, %5, %8, %9\n\t"
+      "v_med3_f32 %6, %6, %8, %9\n\t"
+      "v_med3_f32 %7, %7, %8, %9"
+      : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7])
+      : "s"(lo), "v"(hi));
+  const f32x2 mg2 = {ITA_MAGIC_F, ITA_MAGIC_F};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f32x2 v = (f32x2){f[2 * k], f[2 * k + 1]} + mg2;
+    bits[2 * k] = __float_as_uint(v.x); bits[2 * k + 1] = __float_as_uint(v.y);
   }
 }
 template <typename ACC>

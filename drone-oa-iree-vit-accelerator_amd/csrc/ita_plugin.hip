@@ -15,7 +15,6 @@
 #include "../../include/ita_mi355x.h"
 #include "../../include/ita_weights.h"
 #include "../../include/ita_wire.h"
-#include "ita_encoder_kernel.h"
 #include "ita_f16x3_kernels.h"
 #include "ita_f32_kernels.h"
 #include "ita_int8_kernels.h"
@@ -71,8 +70,6 @@ struct ita_context {
   // derived device buffers
   float* tail_wT = nullptr;
   float* tok_wT = nullptr;                 // [50][E] conv7x7 weights k-major, row 49 = 0
-  float* tok_w16 = nullptr;                // [53][64] for the tokenizer fused into the encoder: rows 49..51 = 0, row 52 = conv
-                                           // bias; channel c of odd row k sits at c ^ 16
   float* wcat[3] = {nullptr, nullptr, nullptr};
   float* bsum[3] = {nullptr, nullptr, nullptr};
   // split-precision (f16 hi/lo) tail: folded tail+decoder matrix and LSTM weights, pre-scaled
@@ -140,8 +137,6 @@ void free_weights(ita_context* c) {
   if (c->tail_wT) (void)hipFree(c->tail_wT);
   if (c->tok_wT) (void)hipFree(c->tok_wT);
   c->tok_wT = nullptr;
-  if (c->tok_w16) (void)hipFree(c->tok_w16);
-  c->tok_w16 = nullptr;
   for (int l = 0; l < 3; ++l) {
     if (c->wcat[l]) (void)hipFree(c->wcat[l]);
     if (c->bsum[l]) (void)hipFree(c->bsum[l]);
@@ -304,6 +299,9 @@ int build_stream_image(const StreamHostParams& p, char** d_out) {
   memcpy(bias + 3 * P, p.bo, E * 4);
   float* ln = (float*)(im.data() + L::LNP);
   if (p.n1w && p.n1b) { memcpy(ln, p.n1w, E * 4); memcpy(ln + E, p.n1b, E * 4); }
+  auto bias_accumulators = [&]() {   // accumulators start at ITA_ACC_BIAS + bias (ita_device.h: scale_clamp_b)
+    for (int i = 0; i < L::NBIAS; ++i) bias[i] = (int32_t)((uint32_t)bias[i] + (uint32_t)ITA_ACC_BIAS);
+  };
   if constexpr (FFN) {
     natural(L::W1, p.w1, F, E);
     fragment(L::W2, p.w2, 4, F);
@@ -321,10 +319,35 @@ int build_stream_image(const StreamHostParams& p, char** d_out) {
           cw[(s * 4 + ct) * 64 + lane] = t < 49 ? p.conv_w[(size_t)ch * 49 + t] : 0.0f;
         }
     memcpy(im.data() + L::CB, p.conv_b, E * 4);
+    int32_t* tap = (int32_t*)(im.data() + L::TAP);
+    for (int t = 0; t < 52; ++t) tap[t] = t < 49 ? (t / 7) * 96 + (t % 7) : 0;
+  }
+  bias_accumulators();
+  {
+    int32_t* vb4 = (int32_t*)(im.data() + L::VB4);
+    for (int d = 0; d < P; ++d)
+      for (int i = 0; i < 4; ++i) vb4[4 * d + i] = bias[2 * P + d];
   }
   HIPCHK(hipMalloc(d_out, im.size()));
   HIPCHK(hipMemcpy(*d_out, im.data(), im.size(), hipMemcpyHostToDevice));
   return ITA_OK;
+}
+
+// The stream kernels read an int32 accumulator as the float 1.5 * 2^23 + sum, which is exact while |sum| < 2^22.
+// Worst case of a Linear row: sum_k |w| * 128 + |bias| (inputs are int8 codes).  QK^T (192 * 128 * 128) and A.V
+// (<= 255 * 128) are inside the range by construction.  A blob outside it runs on the block kernels instead.
+bool stream_range_ok(const StreamHostParams& p, int E, bool ffn) {
+  auto rows_ok = [](const int8_t* w, const int32_t* b, int rows, int k) {
+    for (int r = 0; r < rows; ++r) {
+      long long sum = 0;
+      for (int i = 0; i < k; ++i) sum += w[(size_t)r * k + i] < 0 ? -(long long)w[(size_t)r * k + i] : w[(size_t)r * k + i];
+      const long long bb = b[r] < 0 ? -(long long)b[r] : b[r];
+      if (sum * 128 + bb >= (1ll << 22)) return false;
+    }
+    return true;
+  };
+  return rows_ok(p.wq, p.bq, 192, E) && rows_ok(p.wk, p.bk, 192, E) && rows_ok(p.wv, p.bv, 192, E) &&
+         rows_ok(p.wo, p.bo, E, 192) && (!ffn || (rows_ok(p.w1, p.b1, 256, E) && rows_ok(p.w2, p.b2, E, 256)));
 }
 
 struct StreamIo {
@@ -361,62 +384,50 @@ int launch_stream(ita_context* c, int layer, int mode, bool fuse_ln, const Strea
   } else if (io.img) {
     if (!L.simg_tok) return fail(ITA_ERR_BAD_BLOB, "tokenizer / LayerNorm parameters missing from the blob");
     a.image = L.simg_tok;
-    hipLaunchKernelGGL((ita_stream_kernel<64, true, 1>), dim3(grid), dim3(512), (ItaStreamLds<64, true, true>::TOTAL), s, a);
+    if (io.stamps) hipLaunchKernelGGL((ita_stream_kernel<64, true, 1, true>), dim3(grid), dim3(512), (ItaStreamLds<64, true, true>::TOTAL), s, a);
+    else hipLaunchKernelGGL((ita_stream_kernel<64, true, 1>), dim3(grid), dim3(512), (ItaStreamLds<64, true, true>::TOTAL), s, a);
   } else {
     if (!L.simg_enc) return fail(ITA_ERR_BAD_BLOB, "LayerNorm parameters missing from the blob");
     a.image = L.simg_enc;
-    hipLaunchKernelGGL((ita_stream_kernel<64, true, 0>), dim3(grid), dim3(512), (ItaStreamLds<64, true, false>::TOTAL), s, a);
+    if (io.stamps) hipLaunchKernelGGL((ita_stream_kernel<64, true, 0, true>), dim3(grid), dim3(512), (ItaStreamLds<64, true, false>::TOTAL), s, a);
+    else hipLaunchKernelGGL((ita_stream_kernel<64, true, 0>), dim3(grid), dim3(512), (ItaStreamLds<64, true, false>::TOTAL), s, a);
   }
   HIPCHK(hipGetLastError());
   return ITA_OK;
 }
 
-// whole encoder layer in one launch (E = 64)
+// One encoder layer: the stream kernel (ita_stream_kernel.h) when the layer has an LDS image -- E = 64 and every
+// accumulator provably inside the biased-float range (stream_range_ok) -- else the two block kernels through bufB.
 int launch_encoder(ita_context* c, int layer, const float* x, float* y, _Float16* y_hi, _Float16* y_lo, float* x1_tap,
                    int B, hipStream_t s, unsigned long long* stamps = nullptr, const float* h0_src = nullptr,
                    float* h0_dst = nullptr, const int* slots = nullptr, const void* img = nullptr,
-                   float* tok_tap = nullptr, int img_dtype = ITA_IMAGE_U8) {
+                   float* tok_tap = nullptr) {
   const Layer& L = c->layers[layer];
   if (!L.n1w || !L.n2w) return fail(ITA_ERR_BAD_BLOB, "LayerNorm parameters missing from the blob");
-  static const bool old_enc = getenv("ITA_OLD_ENCODER") != nullptr;   // A/B switch: the barrier-phased kernel of round 1
-  if (!old_enc && !(img && img_dtype != ITA_IMAGE_U8)) {
+  if (img ? L.simg_tok != nullptr : L.simg_enc != nullptr) {
     StreamIo io;
     io.x = x; io.y = y; io.y_hi = y_hi; io.y_lo = y_lo; io.x1_tap = x1_tap; io.stamps = stamps;
     io.h0_src = h0_src; io.h0_dst = h0_dst; io.slots = slots; io.img = img; io.tok_tap = tok_tap;
     return launch_stream(c, layer, 0, false, io, B, s);
   }
-  ItaEncArgs a{};
-  a.x = x; a.y = y; a.y_hi = y_hi; a.y_lo = y_lo; a.x1_tap = x1_tap;
-  a.wq = L.wq; a.wk = L.wk; a.wv = L.wv; a.wo = L.wo; a.w1 = L.w1; a.w2 = L.w2;
-  a.bq = L.bq; a.bk = L.bk; a.bv = L.bv; a.bo = L.bo; a.b1 = L.b1; a.b2 = L.b2;
-  a.inv_sx = L.ascal[ITA_A_INV_SX]; a.mq = L.ascal[ITA_A_MQ]; a.mk = L.ascal[ITA_A_MK]; a.mv = L.ascal[ITA_A_MV];
-  a.ml = L.ascal[ITA_A_ML]; a.mc = L.ascal[ITA_A_MC]; a.mo = L.ascal[ITA_A_MO]; a.so = L.ascal[ITA_A_SO];
-  a.f_inv_sx = L.fscal[ITA_F_INV_SX]; a.m1 = L.fscal[ITA_F_M1]; a.m2 = L.fscal[ITA_F_M2]; a.s2 = L.fscal[ITA_F_S2];
-  a.n1w = L.n1w; a.n1b = L.n1b; a.n2w = L.n2w; a.n2b = L.n2b;
-  a.B = B;
-  a.ld_planes = LDFOLD;
-  a.stamps = stamps;
-  a.h0_src = h0_src; a.h0_dst = h0_dst; a.slots = slots;
-  const int grid = B < c->num_cus ? B : c->num_cus;
-  if (img) {   // tokenizer fused in front: x is not read
-    if (!c->tok_w16 || !c->tok_lw || !c->tok_lb) return fail(ITA_ERR_BAD_BLOB, "tokenizer parameters missing from the blob");
-    a.img = img; a.tok_w = c->tok_w16; a.tok_lnw = c->tok_lw; a.tok_lnb = c->tok_lb; a.tok_tap = tok_tap;
-    if (img_dtype == ITA_IMAGE_U8) hipLaunchKernelGGL(ita_encoder_kernel<1>, dim3(grid), dim3(512), ItaEncLds::TOTAL, s, a);
-    else hipLaunchKernelGGL(ita_encoder_kernel<2>, dim3(grid), dim3(512), ItaEncLds::TOTAL, s, a);
-  } else {
-    hipLaunchKernelGGL(ita_encoder_kernel<0>, dim3(grid), dim3(512), ItaEncLds::TOTAL, s, a);
+  if (img) return fail(ITA_ERR_INVALID_ARG, "launch_encoder: frames need the tokenizer image");
+  int rc = ensure_workspace(c, B);
+  if (rc) return rc;
+  if ((rc = launch_mha(c, layer, x, c->bufB, B, true, nullptr, s))) return rc;
+  if (x1_tap) HIPCHK(hipMemcpyAsync(x1_tap, c->bufB, sizeof(float) * (size_t)B * 128 * c->hdr.E, hipMemcpyDeviceToDevice, s));
+  if (h0_dst) {   // the side copy the stream kernel makes for the LSTM (rows by slot when slots are given: not on this path)
+    if (slots) return fail(ITA_ERR_UNSUPPORTED, "slot-indexed state needs the stream kernel");
+    HIPCHK(hipMemcpyAsync(h0_dst, h0_src, sizeof(float) * (size_t)B * 128, hipMemcpyDeviceToDevice, s));
   }
-  HIPCHK(hipGetLastError());
-  return ITA_OK;
+  return launch_ffn(c, layer, c->bufB, y, B, true, nullptr, s, y_hi, y_lo);
 }
 
 // frames into the E = 64 model: the tokenizer runs inside the first encoder layer's kernel
 // (ITA_SPLIT_TOKENIZER=1 keeps the separate ita_tokenizer_kernel launch, for comparison)
 bool fuse_tokenizer(const ita_context* c, int image_dtype) {
   static const bool split = getenv("ITA_SPLIT_TOKENIZER") != nullptr;
-  static const bool old_enc = getenv("ITA_OLD_ENCODER") != nullptr;
   // f32 frames go through the stand-alone tokenizer: the stream kernel's private pixel windows are sized for bytes
-  return !split && c->hdr.E == 64 && c->tok_w16 && (old_enc || image_dtype == ITA_IMAGE_U8);
+  return !split && image_dtype == ITA_IMAGE_U8 && !c->layers.empty() && c->layers[0].simg_tok;
 }
 
 int launch_tokenizer(ita_context* c, const void* img, int dtype, float* tokens, int B, hipStream_t s) {
@@ -627,11 +638,10 @@ int ita_create(ita_handle* out, int device_ordinal) {
   if ((rc = set_lds(ita_tokenizer_kernel<128, true>, ita_tok_lds_bytes<128>()))) { delete c; return rc; }
   if ((rc = set_lds(ita_tokenizer_kernel<128, false>, ita_tok_lds_bytes<128>()))) { delete c; return rc; }
   if ((rc = set_lds(ita_tail_kernel<64>, ita_tail_lds_bytes<64>()))) { delete c; return rc; }
-  if ((rc = set_lds(ita_encoder_kernel<0>, ItaEncLds::TOTAL))) { delete c; return rc; }
-  if ((rc = set_lds(ita_encoder_kernel<1>, ItaEncLds::TOTAL))) { delete c; return rc; }
-  if ((rc = set_lds(ita_encoder_kernel<2>, ItaEncLds::TOTAL))) { delete c; return rc; }
   if ((rc = set_lds(ita_stream_kernel<64, true, 1>, ItaStreamLds<64, true, true>::TOTAL))) { delete c; return rc; }
   if ((rc = set_lds(ita_stream_kernel<64, true, 0>, ItaStreamLds<64, true, false>::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_stream_kernel<64, true, 1, true>, ItaStreamLds<64, true, true>::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_stream_kernel<64, true, 0, true>, ItaStreamLds<64, true, false>::TOTAL))) { delete c; return rc; }
   if ((rc = set_lds(ita_stream_kernel<64, false, 0>, ItaStreamLds<64, false, false>::TOTAL))) { delete c; return rc; }
   if ((rc = set_lds(ita_stream_kernel<128, false, 0>, ItaStreamLds<128, false, false>::TOTAL))) { delete c; return rc; }
   {
@@ -736,7 +746,8 @@ int ita_load_weights(ita_handle h, const void* blob, size_t nbytes) {
     sp.tlw = hptr<float>(h, "tok.ln_w"); sp.tlb = hptr<float>(h, "tok.ln_b");
     sp.conv_w = hptr<float>(h, "tok.conv_w"); sp.conv_b = hptr<float>(h, "tok.conv_b");
     int rc2 = ITA_OK;
-    const bool lns = sp.n1w && sp.n1b && sp.n2w && sp.n2b;
+    const bool lns = sp.n1w && sp.n1b && sp.n2w && sp.n2b && stream_range_ok(sp, hdr.E, true);
+    if (!stream_range_ok(sp, hdr.E, false)) continue;   // no images: this layer runs on the block kernels
     if (hdr.E == 64) {
       rc2 = build_stream_image<64, false, false>(sp, &L.simg_mha);
       if (!rc2 && lns) rc2 = build_stream_image<64, true, false>(sp, &L.simg_enc);
@@ -753,17 +764,6 @@ int ita_load_weights(ita_handle h, const void* blob, size_t nbytes) {
       for (int k = 0; k < 49; ++k) wT[(size_t)k * Ei + c] = cw[(size_t)c * 49 + k];
     HIPCHK(hipMalloc(&h->tok_wT, wT.size() * sizeof(float)));
     HIPCHK(hipMemcpy(h->tok_wT, wT.data(), wT.size() * sizeof(float), hipMemcpyHostToDevice));
-    const float* cb = hptr<float>(h, "tok.conv_b");
-    if (Ei == 64 && cb) {
-      // rows are read by the MFMA four at a time (k = 4s .. 4s+3 in the four 16-lane groups): odd rows
-      // are stored with the two 16-channel halves of each 32 swapped so the groups hit disjoint LDS banks
-      std::vector<float> w16((size_t)53 * 64, 0.0f);
-      for (int k = 0; k < 49; ++k)
-        for (int c = 0; c < 64; ++c) w16[(size_t)k * 64 + (c ^ ((k & 1) << 4))] = wT[(size_t)k * Ei + c];
-      memcpy(&w16[(size_t)52 * 64], cb, sizeof(float) * 64);
-      HIPCHK(hipMalloc(&h->tok_w16, w16.size() * sizeof(float)));
-      HIPCHK(hipMemcpy(h->tok_w16, w16.data(), w16.size() * sizeof(float), hipMemcpyHostToDevice));
-    }
   }
   // derived: conv3x3 weights re-laid [c][ky][kx][o -> 12] so one tap's 9 output weights are contiguous
   if (const float* cw = hptr<float>(h, "tail.conv_w")) {
@@ -863,17 +863,17 @@ int ita_encoder_layer(ita_handle h, int layer, const float* x, float* y, int bat
   int rc = check(h, batch);
   if (rc) return rc;
   if (!x || !y || layer < 0 || layer >= h->hdr.num_layers) return fail(ITA_ERR_INVALID_ARG, "bad pointer or layer");
-  if (h->hdr.E == 64) return launch_encoder(h, layer, x, y, nullptr, nullptr, nullptr, batch, (hipStream_t)stream);
-  if ((rc = launch_mha(h, layer, x, y, batch, true, nullptr, (hipStream_t)stream))) return rc;
-  return launch_ffn(h, layer, y, y, batch, true, nullptr, (hipStream_t)stream);
+  return launch_encoder(h, layer, x, y, nullptr, nullptr, nullptr, batch, (hipStream_t)stream);
 }
 
 int ita_debug_encoder_stamps(ita_handle h, int layer, const float* x, const void* image_u8, float* y, int batch,
                              unsigned long long* stamps, void* stream) {
   int rc = check(h, batch);
   if (rc) return rc;
-  if ((!x && !image_u8) || !y || !stamps || layer < 0 || layer >= h->hdr.num_layers || h->hdr.E != 64)
+  if ((!x && !image_u8) || !y || !stamps || layer < 0 || layer >= h->hdr.num_layers)
     return fail(ITA_ERR_INVALID_ARG, "bad argument");
+  if (image_u8 ? !h->layers[layer].simg_tok : !h->layers[layer].simg_enc)
+    return fail(ITA_ERR_UNSUPPORTED, "this layer does not run on the stream kernel");
   return launch_encoder(h, layer, x, y, nullptr, nullptr, nullptr, batch, (hipStream_t)stream, stamps, nullptr, nullptr,
                         nullptr, image_u8);
 }
@@ -997,21 +997,13 @@ static int forward_impl(ita_handle h, const void* image, int image_dtype, const 
     const bool last = l == h->hdr.num_layers - 1;
     const bool planes = fast && last;
     float* yout = (planes && !(taps && taps->x2)) ? nullptr : h->bufA;
-    if (h->hdr.E == 64) {     // fused encoder layer, in place on bufA
-      if ((rc = launch_encoder(h, l, h->bufA, yout, planes ? h->x2_hi : nullptr, planes ? h->x2_lo : nullptr,
-                               (taps && last) ? taps->x1 : nullptr, B, s, nullptr, (planes && stage_h0) ? h_in : nullptr,
-                               (planes && stage_h0) ? h->gates : nullptr, slots, (fused_tok && l == 0) ? image : nullptr,
-                               (fused_tok && l == 0 && taps) ? taps->tokens : nullptr, image_dtype))) return rc;
-      MARK();
-      MARK();
-    } else {
-      if ((rc = launch_mha(h, l, h->bufA, h->bufB, B, true, nullptr, s))) return rc;
-      MARK();
-      if (taps && taps->x1 && last) HIPCHK(hipMemcpyAsync(taps->x1, h->bufB, tokb, hipMemcpyDeviceToDevice, s));
-      if ((rc = launch_ffn(h, l, h->bufB, yout, B, true, nullptr, s, planes ? h->x2_hi : nullptr,
-                           planes ? h->x2_lo : nullptr))) return rc;
-      MARK();
-    }
+    // one encoder layer, in place on bufA
+    if ((rc = launch_encoder(h, l, h->bufA, yout, planes ? h->x2_hi : nullptr, planes ? h->x2_lo : nullptr,
+                             (taps && last) ? taps->x1 : nullptr, B, s, nullptr, (planes && stage_h0) ? h_in : nullptr,
+                             (planes && stage_h0) ? h->gates : nullptr, slots, (fused_tok && l == 0) ? image : nullptr,
+                             (fused_tok && l == 0 && taps) ? taps->tokens : nullptr))) return rc;
+    MARK();
+    MARK();
   }
   if (taps && taps->x2) HIPCHK(hipMemcpyAsync(taps->x2, h->bufA, tokb, hipMemcpyDeviceToDevice, s));
   if (fast) {
@@ -1111,8 +1103,8 @@ static int front_impl(ita_handle h, const void* image, int image_dtype, int batc
   for (int l = 0; l < h->hdr.num_layers; ++l) {
     const bool last = l == h->hdr.num_layers - 1;
     if ((rc = launch_encoder(h, l, h->bufA, last ? nullptr : h->bufA, last ? h->x2_hi : nullptr, last ? h->x2_lo : nullptr,
-                             nullptr, batch, s, nullptr, nullptr, nullptr, nullptr, (fused_tok && l == 0) ? image : nullptr, nullptr,
-                             image_dtype))) return rc;
+                             nullptr, batch, s, nullptr, nullptr, nullptr, nullptr, (fused_tok && l == 0) ? image : nullptr,
+                             nullptr))) return rc;
   }
   if ((rc = mark(1, true)) || (rc = mark(3, false))) return rc;
   if (encoder_done_event) HIPCHK(hipEventRecord((hipEvent_t)encoder_done_event, s));

@@ -25,6 +25,9 @@
 // byte windows of the next frame = 159 488 B of the CU's 160 KB.
 #pragma once
 #include "ita_int8_kernels.h"
+#ifndef ITA_ABLATE
+#define ITA_ABLATE 0
+#endif
 
 struct ItaStreamArgs {
   const char* image;      // device copy of the LDS image (ItaStreamLds<...>::IMAGE bytes, built at load time)
@@ -40,13 +43,26 @@ struct ItaStreamArgs {
   // diagnostic only (null in production): waves 0 and 4 of each workgroup store s_memtime at the phase
   // boundaries of the first 8 frames: stamps[((block * 8 + frame) * 2 + (wave >> 2)) * 16 + slot]
   unsigned long long* stamps;
-  // optional side copy for the LSTM that follows (see ita_encoder_kernel.h): h0_src row -> h0_dst[b]
+  // optional side copy for the LSTM that follows: layer-0 hidden state of frame b (row slots[b] or b of h0_src) ->
+  // h0_dst[b].  Layer 0 reads whole rows of h while other workgroups overwrite parts of the same row when the state
+  // is updated in place; the staged copy removes that race.
   const float* h0_src;
   float* h0_dst;
   const int* slots;
   const void* img;        // (B,60,90) u8 wire frames (TOK == 1)
   float* tok_tap;         // optional (B,128,E): the tokens
 };
+
+#ifdef ITA_NO_SCHEDBAR
+#define ITA_SCHED_BARRIER() do {} while (0)
+#else
+#define ITA_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifdef ITA_TOK_AT_END   // experiment: all thirteen conv k-steps after the FFN instead of between its epilogues
+#define ITA_TOK_MID 0
+#else
+#define ITA_TOK_MID 1
+#endif
 
 template <int E, bool FFN, bool TOK>
 struct ItaStreamLds {
@@ -64,7 +80,9 @@ struct ItaStreamLds {
   static constexpr int NLN = 2 * E + (FFN ? 2 * E : 0) + (TOK ? 2 * E : 0);
   static constexpr int CW = LNP + NLN * 4;           // f32 [13][4][64]: conv7x7 weights as 16x16x4 A fragments
   static constexpr int CB = CW + (TOK ? 13 * 4 * 64 * 4 : 0);   // f32 [E]: conv bias
-  static constexpr int IMAGE = CB + (TOK ? E * 4 : 0);
+  static constexpr int TAP = CB + (TOK ? E * 4 : 0);            // int32 [52]: window offset ky * 96 + kx of tap t (0 for t >= 49)
+  static constexpr int VB4 = TAP + (TOK ? 52 * 4 : 0);          // int32 [192][4]: bv replicated (V accumulators start per COLUMN)
+  static constexpr int IMAGE = VB4 + P * 16;
   // ---- built / used at run time
   static constexpr int LUT = IMAGE;                  // f32 [256]: k / 255.0f
   static constexpr int K = LUT + (TOK ? 1024 : 0);   // int8 [12][128][16]  fragment order
@@ -77,8 +95,15 @@ struct ItaStreamLds {
   static_assert(TOTAL <= 160 * 1024, "LDS budget");
 };
 
+// ITA_ABLATE (diagnostic builds only, results are wrong): 1 no requantisation VALU, 2 no int8 MFMA, 4 no tokenizer,
+// 8 no LDS operand reads, 16 no LayerNorm, 32 no softmax, 64 no barriers, 128 no h0 copy / output stores -- what remains is timed against the full kernel to see what a frame's time is made of
 __device__ __forceinline__ i32x4 mfma16(i32x4 a, i32x4 b, i32x4 c) {
+  if constexpr (ITA_ABLATE & 2) return c;   // (operand loads become dead code too)
   return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ i32x4 sfrag(const char* lds, int off) {
+  if constexpr (ITA_ABLATE & 8) return (i32x4){off, off, off, off};
+  return *(const i32x4*)(lds + off);
 }
 // sums / maxima over the four lanes (kq = 0..3) that share a token: lane ^ 16, lane ^ 32.  With both
 // operands the same register the swap leaves {row pairs duplicated} in the two results, so the
@@ -110,6 +135,7 @@ __device__ __forceinline__ int max1632_i(int v) {
 template <int E>
 __device__ __forceinline__ void layernorm_q16(float (&r)[E / 4], const float* w, const float* b, int c0) {
   constexpr int EC = E / 4;
+  if constexpr (ITA_ABLATE & 16) return;
   const float inv_e = 1.0f / (float)E;
   float p = 0.0f;
 #pragma unroll
@@ -130,99 +156,112 @@ __device__ __forceinline__ void layernorm_q16(float (&r)[E / 4], const float* w,
   }
 }
 
-// Four 16-feature output tiles (features 16*tile0 .. 16*tile0+63) of  W . x^T  for this wave's 16 tokens:
-// A = weight rows from a natural-k chunk-major image [E/16][ROWS][16], B = the wave's activation fragments.
-// Requantised and packed: the result is ONE B fragment of the next GEMM (byte 4t+i <-> feature
-// 16*(tile0+t) + 4*kq + i of token qi).
+// ---- software pipeline pieces.  One "group" = four 16-feature output tiles of this wave's 16 tokens.  Its LDS
+// operands (weight fragments + the accumulator initialisers) are fetched one step ahead of its MFMAs, and its
+// requantisation runs one step behind them, so neither the LDS latency nor the MFMA latency is ever waited for:
+//     step g:  load(g+1) | mfma(g) | epilogue(g-1)
+template <int N>
+struct ItaFr {
+  i32x4 w[N];   // weight fragments, tile-major: w[t * (N/4) + k-step]
+};
+// natural-k chunk-major image [E/16][ROWS][16]; the accumulators start from bias rows 16(tile0+t) + 4kq .. +3
 template <int NK, int ROWS>
-__device__ __forceinline__ i32x4 wx_group(const char* w_img, const int* lds_bias, int tile0, const i32x4 (&xf)[NK],
-                                          float mult, float lo, int qi, int kq) {
-  i32x4 acc[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = *(const i32x4*)(lds_bias + (tile0 + t) * 16 + 4 * kq);
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int c = 0; c < NK; ++c)
-      acc[t] = mfma16(lds_frag(w_img, ((NK * kq + c) * ROWS + (tile0 + t) * 16 + qi) << 4), xf[c], acc[t]);
-  float f[16];
+__device__ __forceinline__ void ld_nat(ItaFr<4 * NK>& f, i32x4 (&acc)[4], const char* img, const int* lds_bias, int tile0,
+                                       int qi, int kq) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    float f4[4];
-    scale_clamp<4>(acc[t], mult, lo, f4);
+    acc[t] = *(const i32x4*)(lds_bias + (tile0 + t) * 16 + 4 * kq);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) f[4 * t + i] = f4[i];
+    for (int c = 0; c < NK; ++c) f.w[t * NK + c] = sfrag(img, ((NK * kq + c) * ROWS + (tile0 + t) * 16 + qi) << 4);
   }
-  unsigned p4[4];
-  round_pack16(f, p4);
-  return (i32x4){(int)p4[0], (int)p4[1], (int)p4[2], (int)p4[3]};
 }
-
-// Four output tiles et0 .. et0+3 of a block output projection (out_proj, fc2): A = weight rows from a
-// fragment-order image [4*NKS][E][16] (row et*16 + rho <-> channel (E/4)(rho>>2) + 4 et + (rho&3), so that
-// lane (qi, kq) receives its own channels (E/4)kq + 4 et + i), B = the NKS packed fragments of the previous
-// GEMM.  Returns d[4t+i] = dequantised block output of channel (E/4)kq + 4(et0+t) + i.
-template <int NKS, int E>
-__device__ __forceinline__ void out_group(const char* w_img, const int* lds_bias, int et0, const i32x4 (&bf)[NKS],
-                                          float mult, float scale, int qi, int kq, float (&d)[16]) {
-  i32x4 acc[4];
+// the same image read as the B operand (V projection: roles swapped, column = feature qi): bias is per column
+template <int NK, int ROWS>
+__device__ __forceinline__ void ld_natv(ItaFr<4 * NK>& f, i32x4 (&acc)[4], const char* img, const int* lds_bias, int tile0,
+                                        int qi, int kq) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    acc[t] = *(const i32x4*)(lds_bias + ((tile0 + t) * 16 + qi) * 4);   // replicated table: one 16-byte read, no splat
+#pragma unroll
+    for (int c = 0; c < NK; ++c) f.w[t * NK + c] = sfrag(img, ((NK * kq + c) * ROWS + (tile0 + t) * 16 + qi) << 4);
+  }
+}
+// one k-step (four tiles) of a fragment-order image [4*NKS][E][16] of a block output projection (out_proj, fc2):
+// row 16 et + rho <-> channel (E/4)(rho>>2) + 4 et + (rho&3), so that lane (qi, kq) receives its own channels
+// (E/4)kq + 4 et + i; and its MFMAs
+struct ItaF4 { i32x4 w[4]; };
+template <int E>
+__device__ __forceinline__ void ld_frg_ks(ItaF4& f, const char* img, int et0, int ks, int qi, int kq) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) f.w[t] = sfrag(img, ((4 * ks + kq) * E + (et0 + t) * 16 + qi) << 4);
+}
+__device__ __forceinline__ void mm_ks(const ItaF4& f, const i32x4& x, i32x4 (&acc)[4]) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = mfma16(f.w[t], x, acc[t]);
+}
+template <int E>
+__device__ __forceinline__ void ld_obias(i32x4 (&acc)[4], const int* lds_bias, int et0, int kq) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = *(const i32x4*)(lds_bias + (E / 4) * kq + 4 * (et0 + t));
+}
+// acc[t] += sum_k  W-fragment x activation fragment   (SWAP: the activations are the A operand)
+template <int NKS, bool SWAP>
+__device__ __forceinline__ void mm_group(const ItaFr<4 * NKS>& f, const i32x4 (&x)[NKS], i32x4 (&acc)[4]) {
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks)
-      acc[t] = mfma16(lds_frag(w_img, ((4 * ks + kq) * E + (et0 + t) * 16 + qi) << 4), bf[ks], acc[t]);
+      acc[t] = SWAP ? mfma16(x[ks], f.w[t * NKS + ks], acc[t]) : mfma16(f.w[t * NKS + ks], x[ks], acc[t]);
+}
+// requantise four tiles and pack them: ONE B fragment of the next GEMM (byte 4t+i <-> row 4kq+i of tile t)
+__device__ __forceinline__ i32x4 rq_group(const i32x4 (&acc)[4], float mult, float lo) {
+  if constexpr (ITA_ABLATE & 1) return acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
+#if defined(ITA_RQ_STYLE) && ITA_RQ_STYLE == 1
+  return rq_pack16_c(acc, mult, lo);
+#else
+  return rq_pack16_b(acc, mult, lo);
+#endif
+}
+// block output: d[4t+i] = dequantised int8 code of channel (E/4)kq + 4(et0+t) + i
+__device__ __forceinline__ void dq_group(const i32x4 (&acc)[4], float mult, float scale, float (&d)[16]) {
+  if constexpr (ITA_ABLATE & 1) {
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    float f4[4];
-    scale_clamp<4>(acc[t], mult, -128.0f, f4);
-    // rne of the clamped value is the int8 code; its float is what dequantisation multiplies
-#pragma unroll
-    for (int i = 0; i < 4; ++i) d[4 * t + i] = __builtin_rintf(f4[i]) * scale;
+    for (int i = 0; i < 16; ++i) d[i] = __int_as_float(acc[i >> 2][i & 3]);
+    return;
   }
+#if defined(ITA_RQ_STYLE) && ITA_RQ_STYLE == 1
+  dq16_c(acc, mult, scale, d);
+#else
+  dq16_b(acc, mult, scale, d);
+#endif
 }
 
-template <int E, bool FFN, int TOK>
-__global__ __launch_bounds__(512) void ita_stream_kernel(const ItaStreamArgs a) {
+// (amdgpu_waves_per_eu(2, 2): the workgroup owns the CU's LDS, so two waves per SIMD is all there will ever be -- without
+// it the scheduler trades instruction-level parallelism for registers it has no use for: the LDS size is dynamic)
+template <int E, bool FFN, int TOK, bool STAMP = false>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void ita_stream_kernel(const ItaStreamArgs a) {
   using L = ItaStreamLds<E, FFN, TOK != 0>;
   constexpr int S = 128, P = 192, F = 256, EC = E / 4, NK = E / 64, NTE = E / 16;
   static_assert(!TOK || (E == 64 && FFN), "the fused tokenizer is built for the ITAViTLSTM shape");
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qi = lane & 15, kq = lane >> 4;
-  const int token = wave * 16 + qi;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keep it (and what derives from it) in SGPRs
+  const int qi = lane & 15, kq = lane >> 4, token = wave * 16 + qi;   // (the handful of LDS bases derived from these stay hoisted)
   const int* bias = (const int*)(lds + L::BIAS);
-  const int *l_bq = bias, *l_bk = bias + P, *l_bv = bias + 2 * P, *l_bo = bias + 3 * P, *l_b1 = bias + 3 * P + E,
+  const int *l_bq = bias, *l_bk = bias + P, *l_bo = bias + 3 * P, *l_b1 = bias + 3 * P + E,
             *l_b2 = bias + 3 * P + E + F;
   const float* lnp = (const float*)(lds + L::LNP);
   int* colsum = (int*)(lds + L::COLSUM);
 
-  // ---- once per workgroup: the weight image, every load issued before the first LDS store
-  {
-    constexpr int NP = L::IMAGE / 16, N = (NP + 511) / 512;
-    i32x4 v[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-      const int p = tid + 512 * j;
-      v[j] = (i32x4){0, 0, 0, 0};
-      if (p < NP) v[j] = *(const i32x4*)(a.image + (size_t)p * 16);
-    }
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-      const int p = tid + 512 * j;
-      if (p < NP) *(i32x4*)(lds + p * 16) = v[j];
-    }
-    if constexpr (TOK != 0) {
-      if (tid < 256) ((float*)(lds + L::LUT))[tid] = (float)tid / 255.0f;   // the reference host's float(pixel) / 255.0f (main.cpp:168-169)
-    }
-    if (tid < 2 * P) colsum[tid] = 0;
-  }
-
+  // waves 4-7 were dispatched second and lose every VALU arbitration against their SIMD partner (MI355X guide,
+  // "Two waves per SIMD", item 4): static priority evens the pair out
+#ifndef ITA_NO_SETPRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   int fi = 0;
 #define ITA_SSTAMP(ph)                                                                                  \
   do {                                                                                                  \
-    if (a.stamps && (tid & 255) == 0 && fi < 8)                                                         \
+    if (STAMP && a.stamps && (tid & 255) == 0 && fi < 8)                                                      \
       a.stamps[(((size_t)blockIdx.x * 8 + fi) * 2 + (wave >> 2)) * 16 + (ph)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 
@@ -236,98 +275,165 @@ __global__ __launch_bounds__(512) void ita_stream_kernel(const ItaStreamArgs a) 
   //            (column = token, k = kq) of v_mfma_f32_16x16x4_f32, on gfx950 an exact ascending-k fmaf chain;
   //            the A operand is the conv weight fragment image.  C = lane (token qi, channels 16kq+4ct+i):
   //            the layout the encoder keeps x in.  No patch, no pre-LayerNorm token ever reaches LDS.
-  int tk_y0 = 0, tk_x0 = 0;
-  float tk_h1 = 0.0f, tk_w1 = 0.0f;
+  // Everything per-lane below is derived from an OPAQUE copy of the lane id taken once per frame: otherwise the compiler
+  // hoists ~60 registers of loop-invariant geometry and LDS addresses out of the frame loop, and the kernel (which
+  // lives at the 256-register limit of two waves per SIMD) spills.
   unsigned tk_d[5] = {0, 0, 0, 0, 0};
-  if constexpr (TOK != 0) {
+  struct TokGeo { int y0, x0, rr, pc, row, o; float h1, w1; };
+  auto tok_geo = [&](int ol) {
+    TokGeo g;
     int yp, xp;
-    bilinear_src_dev(wave, 30.0f / 8.0f, 30, tk_y0, yp, tk_h1);    // y0 <= 27 < 29 and x0 <= 43 < 44: the second
-    bilinear_src_dev(qi, 45.0f / 16.0f, 45, tk_x0, xp, tk_w1);     // neighbour is always one row / column on
-  }
-  const int tk_rr = lane / 6, tk_pc = lane - 6 * tk_rr;            // window piece of this lane (lane < 54)
-  const int tk_row = 2 * tk_y0 - 3 + tk_rr;                        // image row (-1 for the top row of wave 0)
-  const int tk_o = tk_row * 90 + 16 * tk_pc - 3;                   // frame byte of the piece's first window byte
-  auto tok_fetch = [&](int fb) {
+    bilinear_src_dev(wave, 30.0f / 8.0f, 30, g.y0, yp, g.h1);        // y0 <= 27 < 29 and x0 <= 43 < 44: the second
+    bilinear_src_dev(ol & 15, 45.0f / 16.0f, 45, g.x0, xp, g.w1);    // neighbour is always one row / column on
+    g.rr = ol / 6; g.pc = ol - 6 * g.rr;                             // window piece of this lane (lane < 54)
+    g.row = 2 * g.y0 - 3 + g.rr;                                     // image row (-1 for the top row of wave 0)
+    g.o = g.row * 90 + 16 * g.pc - 3;                                // frame byte of the piece's first window byte
+    return g;
+  };
+  auto tok_fetch = [&](int fb, int ol) {
+    const TokGeo g = tok_geo(ol);
     const uint8_t* src = (const uint8_t*)a.img + (size_t)fb * 5400;
-    const int a0 = tk_o & ~3;
+    const int a0 = g.o & ~3;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       const int aj = a0 + 4 * j;
       tk_d[j] = 0;
-      if (lane < 54 && tk_row >= 0 && aj >= 0 && aj < 5400) tk_d[j] = *(const unsigned*)(src + aj);
+      if (ol < 54 && g.row >= 0 && aj >= 0 && aj < 5400) tk_d[j] = *(const unsigned*)(src + aj);
     }
   };
-  auto tok_fill = [&]() {
-    const int sh = tk_o & 3;
+  auto tok_fill = [&](int ol) {
+    const TokGeo g = tok_geo(ol);
+    const int sh = g.o & 3;
     unsigned o4[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) o4[j] = __builtin_amdgcn_alignbyte(tk_d[j + 1], tk_d[j], sh);
-    if (tk_pc == 0) o4[0] &= 0xff000000u;        // window columns 0..2  = image columns -3..-1
-    if (tk_pc == 5) o4[3] &= 0x000000ffu;        // window columns 93..95 = image columns 90..92
-    if (lane < 54)
-      *(i32x4*)(lds + L::IMG + wave * L::IMG_WAVE + tk_rr * 96 + 16 * tk_pc) =
+    if (g.pc == 0) o4[0] &= 0xff000000u;        // window columns 0..2  = image columns -3..-1
+    if (g.pc == 5) o4[3] &= 0x000000ffu;        // window columns 93..95 = image columns 90..92
+    if (ol < 54)
+      *(i32x4*)(lds + L::IMG + wave * L::IMG_WAVE + g.rr * 96 + 16 * g.pc) =
           (i32x4){(int)o4[0], (int)o4[1], (int)o4[2], (int)o4[3]};
   };
-  auto tok_compute = [&](int fb, float (&xr)[EC]) {
+  // blend: this lane's 13 taps of its token, and the accumulators started at the conv bias
+  float tk_pt[13];
+  f32x4 tk_acc[4];
+  auto tok_blend = [&](int ol) {
+    const TokGeo g = tok_geo(ol);
+    const int kq = ol >> 4;
     const float* lut = (const float*)(lds + L::LUT);
-    const uint8_t* win = (const uint8_t*)(lds + L::IMG + wave * L::IMG_WAVE);
-    const float h1 = tk_h1, h0 = 1.0f - tk_h1, w1 = tk_w1, w0 = 1.0f - tk_w1;
+    const uint8_t* win = (const uint8_t*)(lds + L::IMG + wave * L::IMG_WAVE) + 2 * g.x0;
+    const int* tap = (const int*)(lds + L::TAP);
+    const float h1 = g.h1, h0 = 1.0f - g.h1, w1 = g.w1, w0 = 1.0f - g.w1;
+    const f32x2 w02 = {w0, w0}, w12 = {w1, w1}, h01 = {h0, h1};
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the window is private to this wave
     __builtin_amdgcn_wave_barrier();
-    float pt[13];
 #pragma unroll
     for (int s = 0; s < 13; ++s) {
-      const int t = 4 * s + kq;
-      int off = 0;                        // taps 49..51 pad K to 52: the zero corner of the window
-      if (t < 49) { const int ky = t / 7; off = ky * 96 + (t - 7 * ky) + 2 * tk_x0; }
-      const float va = lut[win[off]], vb = lut[win[off + 2]], vc = lut[win[off + 192]], vd = lut[win[off + 194]];
-      pt[s] = h0 * (w0 * va + w1 * vb) + h1 * (w0 * vc + w1 * vd);
+      if constexpr (ITA_ABLATE & 512) { tk_pt[s] = h01.x * (float)s; continue; }
+      const int off = tap[4 * s + kq];    // ky * 96 + kx of tap 4s + kq (0 for the pad taps 49..51: their weights are 0)
+      const f32x2 vac = {lut[win[off]], lut[win[off + 192]]}, vbd = {lut[win[off + 2]], lut[win[off + 194]]};
+      const f32x2 r = (w02 * vac + w12 * vbd) * h01;   // {h0 * (w0 a + w1 b), h1 * (w0 c + w1 d)}: the oracle's operations, two per instruction
+      tk_pt[s] = r.x + r.y;
     }
-    ITA_SSTAMP(9);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) tk_acc[ct] = *(const f32x4*)(lds + L::CB + (16 * kq + 4 * ct) * 4);
+  };
+  // one k-step (taps 4s .. 4s+3) of the conv: four f32 MFMAs, placed between the VALU-heavy epilogues of the
+  // int8 phases by the caller (the matrix pipe is otherwise idle there)
+  auto tok_step = [&](int s, int ol) {
     const float* cw = (const float*)(lds + L::CW);
-    f32x4 acc[4];
+    if constexpr (ITA_ABLATE & 1024) { tk_acc[s & 3][0] += tk_pt[s]; return; }
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) acc[ct] = *(const f32x4*)(lds + L::CB + (16 * kq + 4 * ct) * 4);
-#pragma unroll
-    for (int s = 0; s < 13; ++s)
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
-        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(cw[(s * 4 + ct) * 64 + lane], pt[s], acc[ct], 0, 0, 0);
+    for (int ct = 0; ct < 4; ++ct)
+      tk_acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(cw[(s * 4 + ct) * 64 + ol], tk_pt[s], tk_acc[ct], 0, 0, 0);
+  };
+  auto tok_finish = [&](int fb, bool store_tap, float (&xr)[EC], int ol) {
+    const int qi = ol & 15, kq = ol >> 4, token = wave * 16 + qi;
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xr[4 * ct + i] = acc[ct][i];
+      for (int i = 0; i < 4; ++i) xr[4 * ct + i] = tk_acc[ct][i];
     layernorm_q16<E>(xr, lnp + 4 * E, lnp + 5 * E, EC * kq);
-    if (a.tok_tap) {
+    if (a.tok_tap && store_tap) {
       float* o = a.tok_tap + ((size_t)fb * S + token) * E + EC * kq;
 #pragma unroll
       for (int i = 0; i < EC; i += 4) *(f32x4*)(o + i) = (f32x4){xr[i], xr[i + 1], xr[i + 2], xr[i + 3]};
     }
-    ITA_SSTAMP(10);
   };
 
-  // ---- the first frame's input
+  // diagnostic: s_memrealtime (100 MHz, one clock for the whole chip) at kernel entry [12], prologue end [13], exit [14]
+  if (STAMP && a.stamps && (tid & 255) == 0)
+    a.stamps[(((size_t)blockIdx.x * 8) * 2 + (wave >> 2)) * 16 + 12] = __builtin_amdgcn_s_memrealtime();
+  // ---- once per workgroup.  Order matters (it is 10+ % of a 4-frame launch): the first frame's pixels are requested
+  // first, then the tokenizer's tables (the tail of the image), then the 84 KB of weights -- which stay in flight, in
+  // registers, while the first frame is tokenized, and only then go to LDS.
   float xr[EC];
-  if constexpr (TOK != 0) {
-    if ((int)blockIdx.x < a.B) tok_fetch(blockIdx.x);
-  } else if ((int)blockIdx.x < a.B) {
-    const float* xrow = a.x + ((size_t)blockIdx.x * S + token) * E + EC * kq;
+  f32x4 h0_cur = {0.0f, 0.0f, 0.0f, 0.0f};
+  int h0_row_next = 0;
+  {
+    int ol = lane;
+    asm volatile("" : "+v"(ol));
+    if constexpr (TOK != 0) {
+      tok_fetch(blockIdx.x, ol);
+    } else {
+      const float* xrow = a.x + ((size_t)blockIdx.x * S + wave * 16 + (ol & 15)) * E + EC * (ol >> 4);
 #pragma unroll
-    for (int i = 0; i < EC; i += 4) {
-      const f32x4 v = *(const f32x4*)(xrow + i);
-      xr[i] = v.x; xr[i + 1] = v.y; xr[i + 2] = v.z; xr[i + 3] = v.w;
+      for (int i = 0; i < EC; i += 4) {
+        const f32x4 v = *(const f32x4*)(xrow + i);
+        xr[i] = v.x; xr[i + 1] = v.y; xr[i + 2] = v.z; xr[i + 3] = v.w;
+      }
     }
-  }
-  lds_barrier();   // image, table and zeroed column sums are in place
-  if constexpr (TOK != 0) {
-    if ((int)blockIdx.x < a.B) {
-      tok_fill();
-      tok_compute(blockIdx.x, xr);
+    if (a.h0_dst && tid < 32) {
+      const size_t row = a.slots ? (size_t)a.slots[blockIdx.x] : (size_t)blockIdx.x;
+      h0_cur = *(const f32x4*)(a.h0_src + row * 128 + 4 * tid);
     }
+    constexpr int T0 = L::LNP / 16, NT = (L::IMAGE - L::LNP) / 16, NTJ = (NT + 511) / 512;   // tables: LayerNorm, conv, taps
+    constexpr int NW = L::LNP / 16, NWJ = (NW + 511) / 512;                                     // weights + biases
+    static_assert(L::LNP % 16 == 0, "");
+    i32x4 vt[NTJ], vw[NWJ];
+#pragma unroll
+    for (int j = 0; j < NTJ; ++j) {
+      const int p = tid + 512 * j;
+      vt[j] = (i32x4){0, 0, 0, 0};
+      if (p < NT) vt[j] = *(const i32x4*)(a.image + (size_t)(T0 + p) * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < NWJ; ++j) {
+      const int p = tid + 512 * j;
+      vw[j] = (i32x4){0, 0, 0, 0};
+      if (p < NW) vw[j] = *(const i32x4*)(a.image + (size_t)p * 16);
+    }
+    if constexpr (TOK != 0) {
+      if (tid < 256) ((float*)(lds + L::LUT))[tid] = (float)tid / 255.0f;   // the reference host's float(pixel) / 255.0f (main.cpp:168-169)
+    }
+    if (tid < 2 * P) colsum[tid] = ITA_ACC_BIAS;
+#pragma unroll
+    for (int j = 0; j < NTJ; ++j) {
+      const int p = tid + 512 * j;
+      if (p < NT) *(i32x4*)(lds + (T0 + p) * 16) = vt[j];
+    }
+    if constexpr (TOK != 0) {
+      tok_fill(ol);
+      lds_barrier();   // tables and k/255 in place (the weights are still in flight)
+      tok_blend(ol);
+#pragma unroll
+      for (int st = 0; st < 13; ++st) tok_step(st, ol);
+      tok_finish(blockIdx.x, true, xr, ol);
+    }
+#pragma unroll
+    for (int j = 0; j < NWJ; ++j) {
+      const int p = tid + 512 * j;
+      if (p < NW) *(i32x4*)(lds + p * 16) = vw[j];
+    }
+    lds_barrier();   // weights, biases and column-sum bases in place
   }
+  if (STAMP && a.stamps && (tid & 255) == 0)
+    a.stamps[(((size_t)blockIdx.x * 8) * 2 + (wave >> 2)) * 16 + 13] = __builtin_amdgcn_s_memrealtime();
 
   for (int b = blockIdx.x; b < a.B; b += gridDim.x, ++fi) {
+    int ol = lane;
+    asm volatile("" : "+v"(ol));   // see the tokenizer above: its per-lane values are re-derived each frame
     const int nb = b + gridDim.x;
+    const bool more = nb < a.B;   // (uniform) the next frame exists: its tokenizer pieces run between this frame's phases
     int* cs = colsum + (fi & 1) * P;
     ITA_SSTAMP(0);
     // ---------------- quantise: this lane's E/4 channels are its k-slots of the B fragment(s)
@@ -338,61 +444,66 @@ __global__ __launch_bounds__(512) void ita_stream_kernel(const ItaStreamArgs a) 
       q_pack16(&xr[16 * c], a.inv_sx, p4);
       xf[c] = (i32x4){(int)p4[0], (int)p4[1], (int)p4[2], (int)p4[3]};
     }
-    if (a.h0_dst && tid < 32) {
-      const size_t row = a.slots ? (size_t)a.slots[b] : (size_t)b;
-      *(f32x4*)(a.h0_dst + (size_t)b * 128 + 4 * tid) = *(const f32x4*)(a.h0_src + row * 128 + 4 * tid);
+    // side copy of the LSTM layer-0 state row (see ItaStreamArgs): the row was requested a phase ago -- a load waited
+    // for here would hold wave 0, and with it the whole workgroup's next barrier, for a full memory latency
+    if (!(ITA_ABLATE & 128) && a.h0_dst && tid < 32) {
+      *(f32x4*)(a.h0_dst + (size_t)b * 128 + 4 * tid) = h0_cur;
+      if (nb < a.B) h0_row_next = a.slots ? a.slots[nb] : nb;
     }
 
-    // ---------------- projections.  Q stays in registers; K and V^T rows of this wave's 16 tokens go to LDS.
+    // ---------------- projections, nine groups: Q0-2 (stay in registers), K0-2 and V0-2 (this wave's 16 rows of the
+    // K image / 16 columns of the V^T image)
     i32x4 qf[3];
+    {
+      ItaFr<4 * NK> fr[2];
+      i32x4 ac[3][4];
+      auto load = [&](int g, ItaFr<4 * NK>& f, i32x4 (&acc)[4]) {
+        const int mat = g / 3, t0 = 4 * (g - 3 * mat);
+        if (mat == 0) ld_nat<NK, P>(f, acc, lds + L::WQ, l_bq, t0, qi, kq);
+        else if (mat == 1) ld_nat<NK, P>(f, acc, lds + L::WK, l_bk, t0, qi, kq);
+        else ld_natv<NK, P>(f, acc, lds + L::WV, (const int*)(lds + L::VB4), t0, qi, kq);
+      };
+      auto epilogue = [&](int g, const i32x4 (&acc)[4]) {
+        const int mat = g / 3, gg = g - 3 * mat;
+        if (mat == 0) {
+          qf[gg] = rq_group(acc, a.mq, -128.0f);
+        } else if (mat == 1) {
+          *(i32x4*)(lds + L::K + (((4 * gg + kq) * S + token) << 4)) = rq_group(acc, a.mk, -128.0f);
+        } else {
+          // V with the roles swapped (A = tokens, B = weights): lane (feature qi, kq) holds keys 16w + 4kq + i of
+          // feature 16 dt + qi -- one dword of the V^T slot (key block w>>2, k-group kq), at word w&3
+          const i32x4 p4 = rq_group(acc, a.mv, -128.0f);
 #pragma unroll
-    for (int g = 0; g < 3; ++g) qf[g] = wx_group<NK, P>(lds + L::WQ, l_bq, 4 * g, xf, a.mq, -128.0f, qi, kq);
+          for (int t = 0; t < 4; ++t) {
+            const int d = (4 * gg + t) * 16 + qi;
+            *(int*)(lds + L::VT + (((((wave >> 2) * 4 + kq) * P) + d) << 4) + 4 * (wave & 3)) = p4[t];
+            // column sum of the requantised codes for the unsigned-probability offset, kept pre-multiplied by 128
+            atomicAdd(&cs[d], __builtin_amdgcn_sdot4(p4[t], 0x01010101, 0, false) << 7);
+          }
+        }
+      };
+      // (three accumulator sets: group g+1's start from its bias while g computes and g-1 is requantised)
+      load(0, fr[0], ac[0]);
 #pragma unroll
-    for (int g = 0; g < 3; ++g) {
-      const i32x4 kf = wx_group<NK, P>(lds + L::WK, l_bk, 4 * g, xf, a.mk, -128.0f, qi, kq);
-      *(i32x4*)(lds + L::K + (((4 * g + kq) * S + token) << 4)) = kf;
-    }
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {
-      // V with the roles swapped (A = tokens, B = weights): lane (feature qi, kq) gets keys 16w + 4kq + i of
-      // feature 16 dt + qi -- one dword of the V^T slot (key block w>>2, k-group kq), at word w&3
-      i32x4 acc[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int bvv = l_bv[(4 * g + t) * 16 + qi];
-        acc[t] = (i32x4){bvv, bvv, bvv, bvv};
+      for (int g = 0; g < 9; ++g) {
+        if (g + 1 < 9) load(g + 1, fr[(g + 1) & 1], ac[(g + 1) % 3]);
+        if (g < 6) mm_group<NK, false>(fr[g & 1], xf, ac[g % 3]);
+        else mm_group<NK, true>(fr[g & 1], xf, ac[g % 3]);
+        if (g > 0) epilogue(g - 1, ac[(g - 1) % 3]);
+        ITA_SCHED_BARRIER();   // keep the step's loads ahead of the next step's MFMAs
       }
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int c = 0; c < NK; ++c)
-          acc[t] = mfma16(xf[c], lds_frag(lds + L::WV, ((NK * kq + c) * P + (4 * g + t) * 16 + qi) << 4), acc[t]);
-      float f[16];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        float f4[4];
-        scale_clamp<4>(acc[t], a.mv, -128.0f, f4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) f[4 * t + i] = f4[i];
-      }
-      unsigned p4[4];
-      round_pack16(f, p4);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int d = (4 * g + t) * 16 + qi;
-        *(unsigned*)(lds + L::VT + (((((wave >> 2) * 4 + kq) * P) + d) << 4) + 4 * (wave & 3)) = p4[t];
-        // column sum of the requantised codes for the unsigned-probability offset, kept pre-multiplied by 128
-        atomicAdd(&cs[d], __builtin_amdgcn_sdot4((int)p4[t], 0x01010101, 0, false) << 7);
-      }
+      epilogue(8, ac[8 % 3]);
     }
     ITA_SSTAMP(1);
-    lds_barrier();   // B1: K, V^T and the column sums of this frame are complete
+    if constexpr (!(ITA_ABLATE & 64)) lds_barrier();   // B1: K, V^T and the column sums of this frame are complete
     ITA_SSTAMP(2);
 
     // next frame's input: issued now, consumed after the attention phase
+    if (!(ITA_ABLATE & 128) && a.h0_dst && tid < 32 && nb < a.B)
+      h0_cur = *(const f32x4*)(a.h0_src + (size_t)h0_row_next * 128 + 4 * tid);
     float xn[EC];
     if constexpr (TOK != 0) {
-      if (nb < a.B) tok_fetch(nb);
+      if (nb < a.B) tok_fetch(nb, ol);
     } else {
       const float* xnrow = a.x + ((size_t)min(nb, a.B - 1) * S + token) * E + EC * kq;
 #pragma unroll
@@ -404,30 +515,77 @@ __global__ __launch_bounds__(512) void ita_stream_kernel(const ItaStreamArgs a) 
 
     // ---------------- attention for this wave's 16 queries: logits and probabilities stay in registers
     i32x4 cf[3];
+    constexpr int EG = NTE / 4;   // groups of four output tiles of a block output projection
+    ItaF4 ob[2];
+    i32x4 oa[4];
     {
       // logits as packed signed 16-bit pairs: the integer softmax then runs on v_pk_*_16, two keys per
       // VALU op.  w[2kt + j] = {logit 4kt+2j, logit 4kt+2j+1} of keys 16kt + 4kq + ...
       typedef short s16x2 __attribute__((ext_vector_type(2)));
       typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
       s16x2 w[16];
+      struct KFr { i32x4 w[6]; } kfr[2];   // two key tiles x three k-steps
+      ItaF4 vb[2];
+      i32x4 va[3][4];
+      auto ldk = [&](int p, KFr& f) {
 #pragma unroll
-      for (int kt = 0; kt < 8; ++kt) {
-        i32x4 acc = {0, 0, 0, 0};
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks)
-          acc = mfma16(lds_frag(lds + L::K, ((4 * ks + kq) * S + kt * 16 + qi) << 4), qf[ks], acc);
-        float lf[4];
-        scale_clamp<4>(acc, a.ml, -128.0f, lf);
-        unsigned bi[4];
+          for (int ks = 0; ks < 3; ++ks) f.w[t * 3 + ks] = sfrag(lds + L::K, ((4 * ks + kq) * S + (2 * p + t) * 16 + qi) << 4);
+      };
+      // A.V step st = (feature group dg = st >> 1, key block kb = st & 1): four V^T fragments; the accumulators of a
+      // feature group start from 128 * column sum
+      auto ldv = [&](int st, ItaF4& f) {
+        const int dg = st >> 1, kb = st & 1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bi[i] = __float_as_uint(lf[i] + ITA_MAGIC_F);   // low 16 bits = rne(logit), two's complement
+        for (int t = 0; t < 4; ++t) {
+          f.w[t] = sfrag(lds + L::VT, (((kb * 4 + kq) * P) + (4 * dg + t) * 16 + qi) << 4);
+          if (kb == 0) va[dg][t] = *(const i32x4*)(cs + (4 * dg + t) * 16 + 4 * kq);
+        }
+      };
+      i32x4 la[2][2];
+      auto mmk = [&](const KFr& f, i32x4 (&acc)[2]) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          w[2 * kt + j] = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(bi[2 * j + 1], bi[2 * j], 0x05040100u));
+        for (int t = 0; t < 2; ++t) {
+          acc[t] = (i32x4){ITA_ACC_BIAS, ITA_ACC_BIAS, ITA_ACC_BIAS, ITA_ACC_BIAS};
+#pragma unroll
+          for (int ks = 0; ks < 3; ++ks) acc[t] = mfma16(f.w[t * 3 + ks], qf[ks], acc[t]);
+        }
+      };
+      auto epil = [&](int p, const i32x4 (&acc)[2]) {
+        unsigned bi[8];
+#if defined(ITA_RQ_STYLE) && ITA_RQ_STYLE == 1
+        lg8_c(acc, a.ml, bi);
+#else
+        lg8_b(acc, a.ml, bi);   // low 16 bits = rne(logit), two's complement
+#endif
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            w[2 * (2 * p + t) + j] =
+                __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(bi[4 * t + 2 * j + 1], bi[4 * t + 2 * j], 0x05040100u));
+      };
+      ldk(0, kfr[0]);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        if (p + 1 < 4) ldk(p + 1, kfr[(p + 1) & 1]);
+        else ldv(0, vb[0]);
+        mmk(kfr[p & 1], la[p & 1]);
+        if (p > 0) epil(p - 1, la[(p - 1) & 1]);
+        ITA_SCHED_BARRIER();   // keep the step's loads ahead of the next step's MFMAs
       }
+      epil(3, la[1]);
       ITA_SSTAMP(3);
       // integer softmax (models/ITA/QAT/ITA_softmax.py:51-61): shift = max - x, num = 256 >> shift,
       // inv = floor(255 * 2^16 / sum), y = (num * inv) >> 16 = (inv >> 8) >> shift
+      i32x4 pf[2];
+      if constexpr (ITA_ABLATE & 32) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) pf[kb][t] = __builtin_bit_cast(int, w[2 * (4 * kb + t)]);
+      } else {
       s16x2 m2 = w[0];
 #pragma unroll
       for (int j = 1; j < 16; ++j) m2 = __builtin_elementwise_max(m2, w[j]);
@@ -445,7 +603,6 @@ __global__ __launch_bounds__(512) void ita_stream_kernel(const ItaStreamArgs a) 
       sum = max(sum, 1);
       const int inv_hi = ((int)floorf((1.0f / (float)sum) * 16711680.0f)) >> 8;   // <= 255: sum >= 256
       const u16x2 iv = {(unsigned short)inv_hi, (unsigned short)inv_hi};
-      i32x4 pf[2];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -455,48 +612,55 @@ __global__ __launch_bounds__(512) void ita_stream_kernel(const ItaStreamArgs a) 
           const unsigned p23 = __builtin_bit_cast(unsigned, (u16x2)(iv >> sh[2 * kt + 1]));
           pf[kb][t] = (int)(__builtin_amdgcn_perm(p23, p01, 0x06040200u) ^ 0x80808080u);
         }
+      }
       ITA_SSTAMP(4);
       // A.V with uint8 probabilities on a signed MFMA: (p - 128) * v summed + 128 * colsum(v)
 #pragma unroll
-      for (int dg = 0; dg < 3; ++dg) {
-        i32x4 acc[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = *(const i32x4*)(cs + (4 * dg + t) * 16 + 4 * kq);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int kb = 0; kb < 2; ++kb)
-            acc[t] = mfma16(lds_frag(lds + L::VT, (((kb * 4 + kq) * P) + (4 * dg + t) * 16 + qi) << 4), pf[kb], acc[t]);
-        float f[16];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          float f4[4];
-          scale_clamp<4>(acc[t], a.mc, -128.0f, f4);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) f[4 * t + i] = f4[i];
-        }
-        unsigned c4[4];
-        round_pack16(f, c4);
-        cf[dg] = (i32x4){(int)c4[0], (int)c4[1], (int)c4[2], (int)c4[3]};
+      for (int st = 0; st < 6; ++st) {
+        if (st + 1 < 6) ldv(st + 1, vb[(st + 1) & 1]);
+        mm_ks(vb[st & 1], pf[st & 1], va[st >> 1]);
+        if (st == 3) cf[0] = rq_group(va[0], a.mc, -128.0f);
+        ITA_SCHED_BARRIER();   // keep the step's loads ahead of the next step's MFMAs
       }
+      ITA_SSTAMP(5);
+      if constexpr (!(ITA_ABLATE & 64)) lds_barrier();   // B2: every wave is done with K, V^T and this frame's column sums
+      ITA_SSTAMP(6);
+      if (tid < P) cs[tid] = ITA_ACC_BIAS;   // this parity is next accumulated after the NEXT frame's B2
+      ld_frg_ks<E>(ob[0], lds + L::WO, 0, 0, qi, kq);
+      ld_obias<E>(oa, l_bo, 0, kq);
+      // the next frame's pixel window, before this frame's global stores (one in-order vmcnt for loads and stores)
+      if constexpr (TOK != 0) { if (more) tok_fill(ol); }
+      cf[1] = rq_group(va[1], a.mc, -128.0f);
+      ld_frg_ks<E>(ob[1], lds + L::WO, 0, 1, qi, kq);
+      mm_ks(ob[0], cf[0], oa);
+      cf[2] = rq_group(va[2], a.mc, -128.0f);
     }
-    ITA_SSTAMP(5);
-    lds_barrier();   // B2: every wave is done with K, V^T and this frame's column sums
-    ITA_SSTAMP(6);
-    if (tid < P) cs[tid] = 0;   // this parity is next accumulated after the NEXT frame's B2
-    if constexpr (TOK != 0) {
-      if (nb < a.B) tok_fill();   // before this frame's global stores: one in-order vmcnt for loads and stores
-    }
+    if constexpr (TOK != 0 && !(ITA_ABLATE & 4)) { if (more) tok_blend(ol); }
 
-    // ---------------- out_proj + residual + LayerNorm1
+    // ---------------- out_proj + residual + LayerNorm1 (k-step 0 of the first group is already in flight)
     float x1[EC];
+    ItaFr<4 * NK> ffr[2];
+    i32x4 fa[3][4];
 #pragma unroll
-    for (int eg = 0; eg < NTE / 4; ++eg) {
+    for (int eg = 0; eg < EG; ++eg) {
+      // k-steps 3 eg + ks; fragments are fetched one k-step ahead
+#pragma unroll
+      for (int ks = (eg == 0 ? 1 : 0); ks < 3; ++ks) {
+        const int cur = (3 * eg + ks) & 1;
+        if (ks + 1 < 3) ld_frg_ks<E>(ob[cur ^ 1], lds + L::WO, 4 * eg, ks + 1, qi, kq);
+        else if (eg + 1 < EG) ld_frg_ks<E>(ob[cur ^ 1], lds + L::WO, 4 * (eg + 1), 0, qi, kq);
+        else if constexpr (FFN) ld_nat<NK, F>(ffr[0], fa[0], lds + L::W1, l_b1, 0, qi, kq);
+        mm_ks(ob[cur], cf[ks], oa);
+        ITA_SCHED_BARRIER();   // keep the step's loads ahead of the next step's MFMAs
+      }
+      if constexpr (TOK != 0 && ITA_TOK_MID && !(ITA_ABLATE & 4)) { if (more) { tok_step(0, ol); tok_step(1, ol); } }
       float d[16];
-      out_group<3, E>(lds + L::WO, l_bo, 4 * eg, cf, a.mo, a.so, qi, kq, d);
+      dq_group(oa, a.mo, a.so, d);
+      if (eg + 1 < EG) ld_obias<E>(oa, l_bo, 4 * (eg + 1), kq);
 #pragma unroll
       for (int j = 0; j < 16; ++j) x1[16 * eg + j] = (FFN || a.fuse_ln) ? xr[16 * eg + j] + d[j] : d[j];
     }
+    if constexpr (TOK != 0 && ITA_TOK_MID && !(ITA_ABLATE & 4)) { if (more) { tok_step(2, ol); tok_step(3, ol); } }
     if (FFN || a.fuse_ln) layernorm_q16<E>(x1, lnp, lnp + E, EC * kq);
     if (a.x1_tap) {
       float* o = a.x1_tap + ((size_t)b * S + token) * E + EC * kq;
@@ -507,7 +671,9 @@ __global__ __launch_bounds__(512) void ita_stream_kernel(const ItaStreamArgs a) 
 
     float yv[EC];
     if constexpr (FFN) {
-      // ---------------- FFN: fc1 + ReLU (hidden layer = four B fragments in registers) -> fc2 -> LayerNorm2
+      // ---------------- FFN: fc1 + ReLU (hidden layer = four B fragments in registers) -> fc2 -> LayerNorm2.
+      // fc2's k-step ks consumes hidden fragment ks: its MFMAs are issued one step behind fc1's epilogue.
+      static_assert(!FFN || EG == 1, "the fused FFN is written for E = 64");
       i32x4 x1f[NK];
 #pragma unroll
       for (int c = 0; c < NK; ++c) {
@@ -515,17 +681,29 @@ __global__ __launch_bounds__(512) void ita_stream_kernel(const ItaStreamArgs a) 
         q_pack16(&x1[16 * c], a.f_inv_sx, p4);
         x1f[c] = (i32x4){(int)p4[0], (int)p4[1], (int)p4[2], (int)p4[3]};
       }
-      i32x4 hf[4];
+      i32x4 hf[4], ya[4];
+      ItaF4 wb[2];
+      ld_obias<E>(ya, l_b2, 0, kq);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) hf[g] = wx_group<NK, F>(lds + L::W1, l_b1, 4 * g, x1f, a.m1, 0.0f, qi, kq);
-      ITA_SSTAMP(8);
-#pragma unroll
-      for (int eg = 0; eg < NTE / 4; ++eg) {
-        float d[16];
-        out_group<4, E>(lds + L::W2, l_b2, 4 * eg, hf, a.m2, a.s2, qi, kq, d);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) yv[16 * eg + j] = x1[16 * eg + j] + d[j];
+      for (int g = 0; g < 4; ++g) {
+        if (g + 1 < 4) ld_nat<NK, F>(ffr[(g + 1) & 1], fa[(g + 1) % 3], lds + L::W1, l_b1, 4 * (g + 1), qi, kq);
+        if (g >= 1) ld_frg_ks<E>(wb[(g - 1) & 1], lds + L::W2, 0, g - 1, qi, kq);
+        mm_group<NK, false>(ffr[g & 1], x1f, fa[g % 3]);
+        if (g >= 2) mm_ks(wb[(g - 2) & 1], hf[g - 2], ya);
+        if constexpr (TOK != 0 && ITA_TOK_MID && !(ITA_ABLATE & 4)) { if (more) { tok_step(4 + 2 * g, ol); tok_step(5 + 2 * g, ol); } }
+        if (g >= 1) hf[g - 1] = rq_group(fa[(g - 1) % 3], a.m1, 0.0f);
+        ITA_SCHED_BARRIER();   // keep the step's loads ahead of the next step's MFMAs
       }
+      ld_frg_ks<E>(wb[1], lds + L::W2, 0, 3, qi, kq);
+      mm_ks(wb[0], hf[2], ya);
+      hf[3] = rq_group(fa[3 % 3], a.m1, 0.0f);
+      mm_ks(wb[1], hf[3], ya);
+      if constexpr (TOK != 0 && ITA_TOK_MID && !(ITA_ABLATE & 4)) { if (more) tok_step(12, ol); }
+      ITA_SSTAMP(8);
+      float d[16];
+      dq_group(ya, a.m2, a.s2, d);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) yv[j] = x1[j] + d[j];
       layernorm_q16<E>(yv, lnp + 2 * E, lnp + 3 * E, EC * kq);
     } else {
 #pragma unroll
@@ -537,7 +715,7 @@ __global__ __launch_bounds__(512) void ita_stream_kernel(const ItaStreamArgs a) 
 #pragma unroll
         for (int i = 0; i < EC; i += 4) *(f32x4*)(a.y + o + i) = (f32x4){yv[i], yv[i + 1], yv[i + 2], yv[i + 3]};
       }
-      if (a.y_hi) {
+      if (!(ITA_ABLATE & 128) && a.y_hi) {
         typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #pragma unroll
         for (int i = 0; i < EC; i += 8) {
@@ -549,19 +727,31 @@ __global__ __launch_bounds__(512) void ita_stream_kernel(const ItaStreamArgs a) 
             vl[j] = (_Float16)(yv[i + j] - (float)hh);
           }
           const size_t po = (size_t)b * a.ld_planes + token * E + EC * kq + i;
-          *(h8*)(a.y_hi + po) = vh;
-          *(h8*)(a.y_lo + po) = vl;
+          if constexpr (ITA_ABLATE & 256) {   // values stay live, one 2-byte store instead of two 16-byte ones
+            a.y_hi[po] = vh[0] + vh[1] + vh[2] + vh[3] + vh[4] + vh[5] + vh[6] + vh[7] + vl[0] + vl[1] + vl[2] + vl[3] + vl[4] + vl[5] + vl[6] + vl[7];
+          } else {
+            *(h8*)(a.y_hi + po) = vh;
+            *(h8*)(a.y_lo + po) = vl;
+          }
         }
       }
     }
     ITA_SSTAMP(11);
     // ---------------- the next frame's tokens
-    if constexpr (TOK != 0) {
-      if (nb < a.B) tok_compute(nb, xr);
+    if constexpr (TOK != 0 && !(ITA_ABLATE & 4)) {
+      if constexpr (!ITA_TOK_MID) {
+        if (more) {
+#pragma unroll
+          for (int st = 0; st < 13; ++st) tok_step(st, ol);
+        }
+      }
+      if (more) tok_finish(nb, true, xr, ol);
     } else {
 #pragma unroll
       for (int i = 0; i < EC; ++i) xr[i] = xn[i];
     }
   }
+  if (STAMP && a.stamps && (tid & 255) == 0)
+    a.stamps[(((size_t)blockIdx.x * 8) * 2 + (wave >> 2)) * 16 + 14] = __builtin_amdgcn_s_memrealtime();
 #undef ITA_SSTAMP
 }

@@ -29,5 +29,12 @@ for wv in (0, 1):
         print(f"  {n:20s} {np.median(dt):9.0f} {np.percentile(dt, 90):9.0f}")
     nxt = st[:, 2:5, wv, 0] - st[:, 1:4, wv, 0]
     print(f"  frame period         {np.median(nxt):9.0f} {np.percentile(nxt, 90):9.0f}")
+# constant-clock (100 MHz) timeline of the launch: entry / prologue end / exit of every workgroup
+t0 = st[:, 0, :, 12].min()
+ent, pro, ext = st[:, 0, :, 12] - t0, st[:, 0, :, 13] - t0, st[:, 0, :, 14] - t0
+us = lambda v: v / 100.0
+print(f"launch timeline (us from the first workgroup's entry): entry median {us(np.median(ent)):.2f} max {us(ent.max()):.2f} | "
+      f"prologue end median {us(np.median(pro)):.2f} max {us(pro.max()):.2f} | exit median {us(np.median(ext)):.2f} max {us(ext.max()):.2f}")
+print(f"prologue length median {us(np.median(pro - ent)):.2f} us p90 {us(np.percentile(pro - ent, 90)):.2f}; frames part median {us(np.median(ext - pro)):.2f} us")
 whole = st[:, 3, 0, 11] - st[:, 0, 0, 0]
 print(f"4 frames (wg) median {np.median(whole):9.0f}; first-frame start spread {st[:, 0, 0, 0].max() - st[:, 0, 0, 0].min()}")

@@ -18,7 +18,7 @@ rows.sort()
 short = lambda n: n.split("(")[0].split("<")[0].replace("void ", "")[:28]
 # a step starts at every tokenizer launch
 steps, cur = [], None
-first = "tokenizer" if any("tokenizer" in n for _, _, n in rows) else "ita_encoder_kernel"   # first kernel of a step
+first = "tokenizer" if any("tokenizer" in n for _, _, n in rows) else "ita_stream_kernel"   # first kernel of a step
 for s, e, n in rows:
     if first in n:
         cur = []
