@@ -408,6 +408,24 @@ __global__ __launch_bounds__(256) void ita_lstm_layer_kernel(const ItaLstmLayerA
   }
 }
 
+// f32 rows -> the hi / lo f16 planes the split-precision GEMM reads (the encoder kernels write them directly;
+// this is for ita_vitlstm_tail, which starts from a given activation): eight values per thread
+__global__ void ita_split_planes_kernel(const float* __restrict__ x, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                        int width, int ld, int rows) {
+  const size_t i8 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i8 >= (size_t)rows * width) return;
+  const size_t r = i8 / width, c = i8 - r * width;
+  f16x8 vh, vl;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    _Float16 a, b;
+    split_f16(x[i8 + j], a, b);
+    vh[j] = a; vl[j] = b;
+  }
+  *(f16x8*)(hi + r * ld + c) = vh;
+  *(f16x8*)(lo + r * ld + c) = vl;
+}
+
 // one-hot rows for the load-time folding: x[i][col0 + i] = 1
 __global__ void ita_impulse_kernel(float* x, int rows, int width, int col0) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -86,6 +86,8 @@ struct ita_context {
   float* part = nullptr;
   // workspace
   int cap = 0;
+  bool ws_reserved = false;     // ita_reserve was called: the workspace is pinned (see ensure_workspace)
+  int front_cap[2] = {0, 0};    // workspace capacity when ita_vitlstm_front filled partial buffer 0 / 1
   float *bufA = nullptr, *bufB = nullptr, *cat0 = nullptr, *cat1 = nullptr, *cat2 = nullptr, *gates = nullptr,
         *feat = nullptr;
   // per-stage profiling (ita_profile_begin / _end)
@@ -169,10 +171,19 @@ void free_workspace(ita_context* c) {
   if (c->part) (void)hipFree(c->part);
   c->part = nullptr;
   c->cap = 0;
+  c->front_cap[0] = c->front_cap[1] = 0;
 }
 
-int ensure_workspace(ita_context* c, int B) {
+// Growth frees and reallocates every buffer, so it is only allowed while nothing can still reference the old ones:
+// never after an explicit ita_reserve (HIP graphs and front/back pairs keep raw pointers into the workspace), and never
+// on a stream that is being captured.
+int ensure_workspace(ita_context* c, int B, hipStream_t s = nullptr) {
   if (B <= c->cap) return ITA_OK;
+  if (c->ws_reserved)
+    return fail(ITA_ERR_INVALID_ARG, "batch exceeds the workspace pinned by ita_reserve; call ita_reserve(max_batch) again while idle");
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+    return fail(ITA_ERR_INVALID_ARG, "the workspace cannot grow inside a stream capture; call ita_reserve first");
   free_workspace(c);
   const size_t E = (size_t)c->hdr.E;
   HIPCHK(hipMalloc(&c->bufA, sizeof(float) * B * 128 * E));
@@ -691,6 +702,11 @@ int ita_load_weights(ita_handle h, const void* blob, size_t nbytes) {
           (e[i].offset & 15))
         return fail(ITA_ERR_BAD_BLOB, "tensor out of bounds or misaligned");
   }
+  {
+    char bad[32];
+    const int v = ita_blob_validate(blob, nbytes, bad);
+    if (v) return fail(ITA_ERR_BAD_BLOB, std::string(v == -2 ? "required tensor missing: " : v == -3 ? "tensor has the wrong dtype or size: " : "malformed blob ") + bad);
+  }
   free_weights(h);
   free_workspace(h);
   h->hdr = hdr;
@@ -820,10 +836,20 @@ int ita_load_weights(ita_handle h, const void* blob, size_t nbytes) {
   return ITA_OK;
 }
 
+int ita_validate_blob(const void* blob, size_t nbytes, char* bad_name32) {
+  const int v = ita_blob_validate(blob, nbytes, bad_name32);
+  if (v) return fail(ITA_ERR_BAD_BLOB, std::string("blob validation failed (") + std::to_string(v) + ")");
+  return ITA_OK;
+}
+
 int ita_reserve(ita_handle h, int max_batch) {
   int rc = check(h, max_batch);
   if (rc) return rc;
-  return ensure_workspace(h, max_batch);
+  h->ws_reserved = false;          // an explicit reserve may move the workspace: the caller vouches that nothing is in flight
+  if (max_batch > h->cap) HIPCHK(hipDeviceSynchronize());
+  rc = ensure_workspace(h, max_batch);
+  h->ws_reserved = rc == ITA_OK;
+  return rc;
 }
 
 int ita_get_dims(ita_handle h, int* E, int* S, int* P, int* F, int* H, int* num_layers) {
@@ -876,6 +902,15 @@ int ita_debug_encoder_stamps(ita_handle h, int layer, const float* x, const void
     return fail(ITA_ERR_UNSUPPORTED, "this layer does not run on the stream kernel");
   return launch_encoder(h, layer, x, y, nullptr, nullptr, nullptr, batch, (hipStream_t)stream, stamps, nullptr, nullptr,
                         nullptr, image_u8);
+}
+
+int ita_debug_softmax_rows(ita_handle h, const int8_t* logits, uint8_t* probs, int rows, void* stream) {
+  int rc = check(h, rows, false);
+  if (rc) return rc;
+  if (!logits || !probs) return fail(ITA_ERR_INVALID_ARG, "null pointer");
+  hipLaunchKernelGGL(ita_softmax_rows_kernel, dim3((rows + 15) / 16), dim3(64), 0, (hipStream_t)stream, logits, probs, rows);
+  HIPCHK(hipGetLastError());
+  return ITA_OK;
 }
 
 int ita_tokenizer(ita_handle h, const void* image, int image_dtype, float* tokens, int batch, void* stream) {
@@ -954,17 +989,19 @@ int ita_fusion_tail_large(ita_handle h, const float* x, float* out, int batch, i
   }
 }
 
+// x2_in != null: start behind the encoder from a given (B,128,E) activation (ita_vitlstm_tail); image is then unused
 static int forward_impl(ita_handle h, const void* image, int image_dtype, const float* desvel, const float* quat,
                         const float* h_in, const float* c_in, float* vel, float* h_out, float* c_out, int batch,
-                        const ita_forward_taps* taps, void* stream, const int* slots, int state_rows) {
+                        const ita_forward_taps* taps, void* stream, const int* slots, int state_rows,
+                        const float* x2_in = nullptr) {
   int rc = check(h, batch);
   if (rc) return rc;
-  if (!image || !desvel || !quat || !h_in || !c_in || !vel || !h_out || !c_out)
+  if ((!image && !x2_in) || !desvel || !quat || !h_in || !c_in || !vel || !h_out || !c_out)
     return fail(ITA_ERR_INVALID_ARG, "null pointer");
   if (image_dtype != ITA_IMAGE_F32 && image_dtype != ITA_IMAGE_U8) return fail(ITA_ERR_INVALID_ARG, "bad image dtype");
   if (!h->hdr.has_tail || !h->dec_w || !h->wcat[0] || !h->fc_w)
     return fail(ITA_ERR_BAD_BLOB, "blob holds no tail / decoder / LSTM parameters");
-  if ((rc = ensure_workspace(h, batch))) return rc;
+  if ((rc = ensure_workspace(h, batch, (hipStream_t)stream))) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int B = batch;
   const size_t tokb = sizeof(float) * (size_t)B * 128 * h->hdr.E;
@@ -989,11 +1026,20 @@ static int forward_impl(ita_handle h, const void* image, int image_dtype, const 
   }
 #define MARK() do { if (ev && (h->prof_stage < 0 || evi == m_lo || evi == m_hi)) HIPCHK(hipEventRecord(ev[evi], s)); ++evi; } while (0)
   MARK();
-  const bool fused_tok = fuse_tokenizer(h, image_dtype);
-  if (!fused_tok && (rc = launch_tokenizer(h, image, image_dtype, h->bufA, B, s))) return rc;
+  const bool fused_tok = !x2_in && fuse_tokenizer(h, image_dtype);
+  if (x2_in) {
+    HIPCHK(hipMemcpyAsync(h->bufA, x2_in, tokb, hipMemcpyDeviceToDevice, s));
+    if (fast) {
+      const size_t n = (size_t)B * 128 * h->hdr.E;
+      hipLaunchKernelGGL(ita_split_planes_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, s, h->bufA, h->x2_hi,
+                         h->x2_lo, 128 * h->hdr.E, LDFOLD, B);
+      HIPCHK(hipGetLastError());
+    }
+    if (stage_h0) HIPCHK(hipMemcpyAsync(h->gates, h_in, sizeof(float) * (size_t)B * 128, hipMemcpyDeviceToDevice, s));
+  } else if (!fused_tok && (rc = launch_tokenizer(h, image, image_dtype, h->bufA, B, s))) return rc;
   MARK();
-  if (!fused_tok && taps && taps->tokens) HIPCHK(hipMemcpyAsync(taps->tokens, h->bufA, tokb, hipMemcpyDeviceToDevice, s));
-  for (int l = 0; l < h->hdr.num_layers; ++l) {
+  if (!x2_in && !fused_tok && taps && taps->tokens) HIPCHK(hipMemcpyAsync(taps->tokens, h->bufA, tokb, hipMemcpyDeviceToDevice, s));
+  for (int l = 0; l < (x2_in ? 0 : h->hdr.num_layers); ++l) {
     const bool last = l == h->hdr.num_layers - 1;
     const bool planes = fast && last;
     float* yout = (planes && !(taps && taps->x2)) ? nullptr : h->bufA;
@@ -1005,6 +1051,7 @@ static int forward_impl(ita_handle h, const void* image, int image_dtype, const 
     MARK();
     MARK();
   }
+  if (x2_in) { MARK(); MARK(); }
   if (taps && taps->x2) HIPCHK(hipMemcpyAsync(taps->x2, h->bufA, tokb, hipMemcpyDeviceToDevice, s));
   if (fast) {
     // folded tail+decoder: dec = x2 . Wfold^T + bias'   (x2 planes were written by the last FFN)
@@ -1074,6 +1121,13 @@ int ita_vitlstm_forward(ita_handle h, const void* image, int image_dtype, const 
   return forward_impl(h, image, image_dtype, desvel, quat, h_in, c_in, vel, h_out, c_out, batch, taps, stream, nullptr, 0);
 }
 
+int ita_vitlstm_tail(ita_handle h, const float* x2, const float* desvel, const float* quat, const float* h_in,
+                     const float* c_in, float* vel, float* h_out, float* c_out, int batch, void* stream) {
+  if (!x2) return fail(ITA_ERR_INVALID_ARG, "null pointer");
+  if (h && h->loaded && h->hdr.E != 64) return fail(ITA_ERR_UNSUPPORTED, "the fusion tail is built for E = 64 (ITAViTLSTM)");
+  return forward_impl(h, nullptr, ITA_IMAGE_F32, desvel, quat, h_in, c_in, vel, h_out, c_out, batch, nullptr, stream, nullptr, 0, x2);
+}
+
 // ---- two-stage form for software pipelining across time steps -------------------------------------
 static int front_impl(ita_handle h, const void* image, int image_dtype, int batch, int buf, void* stream,
                       void* encoder_done_event) {
@@ -1082,7 +1136,8 @@ static int front_impl(ita_handle h, const void* image, int image_dtype, int batc
   if (!image || (buf != 0 && buf != 1)) return fail(ITA_ERR_INVALID_ARG, "null image or buf not in {0,1}");
   if (image_dtype != ITA_IMAGE_F32 && image_dtype != ITA_IMAGE_U8) return fail(ITA_ERR_INVALID_ARG, "bad image dtype");
   if (!(h->tail_mode == 1 && h->folded)) return fail(ITA_ERR_UNSUPPORTED, "front/back form needs tail mode 1 and a full ITAViTLSTM blob");
-  if ((rc = ensure_workspace(h, batch))) return rc;
+  if ((rc = ensure_workspace(h, batch, (hipStream_t)stream))) return rc;
+  h->front_cap[buf] = h->cap;
   hipStream_t s = (hipStream_t)stream;
   // sampled single-stage profiling (ita_profile_begin_sampled with only_stage 0, 1 or 3) also works here
   const int L2 = 2 * h->hdr.num_layers, per = 5 + L2;
@@ -1132,7 +1187,8 @@ int ita_vitlstm_back(ita_handle h, const float* desvel, const float* quat, const
   if (!desvel || !quat || !h_in || !c_in || !vel || !h_out || !c_out || (buf != 0 && buf != 1))
     return fail(ITA_ERR_INVALID_ARG, "null pointer or buf not in {0,1}");
   if (!(h->tail_mode == 1 && h->folded)) return fail(ITA_ERR_UNSUPPORTED, "front/back form needs tail mode 1 and a full ITAViTLSTM blob");
-  if (batch > h->cap) return fail(ITA_ERR_INVALID_ARG, "ita_vitlstm_front has not run for this batch size");
+  if (batch > h->cap || h->front_cap[buf] != h->cap)
+    return fail(ITA_ERR_INVALID_ARG, "ita_vitlstm_front has not filled this buffer for the current workspace (reserve before front)");
   hipStream_t s = (hipStream_t)stream;
   const int B = batch;
   const size_t lstride = (size_t)B * 128;

@@ -156,6 +156,68 @@ __device__ __forceinline__ void layernorm_q16(float (&r)[E / 4], const float* w,
   }
 }
 
+// Integer softmax (models/ITA/QAT/ITA_softmax.py:51-61) of the 16 rows a wave holds as packed signed 16-bit logit pairs
+// -- lane (qi, kq): w[2kt + j] = {logit, logit'} of keys 16kt + 4kq + 2j, +1 of row qi -- entirely on v_pk_*_16, two keys
+// per VALU op:  shift = max - x,  num = 256 >> shift,  inv = floor(255 * 2^16 / sum),  y = (num * inv) >> 16 = (inv >> 8)
+// >> shift.  Out: the A.V MFMA's B fragments, pf[kb] byte 4t+i = (y - 128) of key 64kb + 16t + 4kq + i (the u8
+// probabilities ride a signed MFMA as p - 128; the 128 * colsum(V) term restores them).
+typedef short ita_s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short ita_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ita_softmax_packed16(const ita_s16x2 (&w)[16], i32x4 (&pf)[2]) {
+  typedef ita_s16x2 s16x2;
+  typedef ita_u16x2 u16x2;
+  s16x2 m2 = w[0];
+#pragma unroll
+  for (int j = 1; j < 16; ++j) m2 = __builtin_elementwise_max(m2, w[j]);
+  const int m = max1632_i(max((int)m2.x, (int)m2.y));
+  const s16x2 mm = {(short)m, (short)m};
+  const s16x2 cap = {15, 15};                  // 256 >> s and inv_hi >> s are both 0 from s = 9 on
+  const u16x2 one = {256, 256};
+  u16x2 sh[16], sum2 = {0, 0};
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    sh[j] = __builtin_bit_cast(u16x2, __builtin_elementwise_min((s16x2)(mm - w[j]), cap));
+    sum2 += one >> sh[j];
+  }
+  int sum = sum1632_i((int)sum2.x + (int)sum2.y);   // <= 16 * 256 per half: no 16-bit overflow
+  sum = max(sum, 1);
+  const int inv_hi = ((int)floorf((1.0f / (float)sum) * 16711680.0f)) >> 8;   // <= 255: sum >= 256
+  const u16x2 iv = {(unsigned short)inv_hi, (unsigned short)inv_hi};
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int kt = 4 * kb + t;
+      const unsigned p01 = __builtin_bit_cast(unsigned, (u16x2)(iv >> sh[2 * kt]));
+      const unsigned p23 = __builtin_bit_cast(unsigned, (u16x2)(iv >> sh[2 * kt + 1]));
+      pf[kb][t] = (int)(__builtin_amdgcn_perm(p23, p01, 0x06040200u) ^ 0x80808080u);
+    }
+}
+
+// Test entry for that function alone: rows of int8 logits (R,128) -> u8 probabilities, 16 rows per wave in exactly the
+// register layout the encoder kernel has them in.  Lets the parity tests feed chosen rows (all equal, one-hot, the
+// shift 8 / 9 boundary, +-127 / -128) through the GPU formulation, which otherwise only ever sees what QK^T produces.
+__global__ __launch_bounds__(64) void ita_softmax_rows_kernel(const int8_t* __restrict__ logits, uint8_t* __restrict__ probs, int rows) {
+  const int lane = threadIdx.x, qi = lane & 15, kq = lane >> 4;
+  const int row = min((int)blockIdx.x * 16 + qi, rows - 1);
+  ita_s16x2 w[16];
+#pragma unroll
+  for (int kt = 0; kt < 8; ++kt) {
+    const int v = *(const int*)(logits + (size_t)row * 128 + 16 * kt + 4 * kq);
+    w[2 * kt] = (ita_s16x2){(short)(int8_t)v, (short)(int8_t)(v >> 8)};
+    w[2 * kt + 1] = (ita_s16x2){(short)(int8_t)(v >> 16), (short)(int8_t)(v >> 24)};
+  }
+  i32x4 pf[2];
+  ita_softmax_packed16(w, pf);
+  if ((int)blockIdx.x * 16 + qi < rows) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        *(unsigned*)(probs + (size_t)row * 128 + 64 * kb + 16 * t + 4 * kq) = (unsigned)pf[kb][t] ^ 0x80808080u;
+  }
+}
+
 // ---- software pipeline pieces.  One "group" = four 16-feature output tiles of this wave's 16 tokens.  Its LDS
 // operands (weight fragments + the accumulator initialisers) are fetched one step ahead of its MFMAs, and its
 // requantisation runs one step behind them, so neither the LDS latency nor the MFMA latency is ever waited for:
@@ -521,8 +583,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     {
       // logits as packed signed 16-bit pairs: the integer softmax then runs on v_pk_*_16, two keys per
       // VALU op.  w[2kt + j] = {logit 4kt+2j, logit 4kt+2j+1} of keys 16kt + 4kq + ...
-      typedef short s16x2 __attribute__((ext_vector_type(2)));
-      typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+      typedef ita_s16x2 s16x2;
       s16x2 w[16];
       struct KFr { i32x4 w[6]; } kfr[2];   // two key tiles x three k-steps
       ItaF4 vb[2];
@@ -577,8 +638,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
       epil(3, la[1]);
       ITA_SSTAMP(3);
-      // integer softmax (models/ITA/QAT/ITA_softmax.py:51-61): shift = max - x, num = 256 >> shift,
-      // inv = floor(255 * 2^16 / sum), y = (num * inv) >> 16 = (inv >> 8) >> shift
       i32x4 pf[2];
       if constexpr (ITA_ABLATE & 32) {
 #pragma unroll
@@ -586,32 +645,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
           for (int t = 0; t < 4; ++t) pf[kb][t] = __builtin_bit_cast(int, w[2 * (4 * kb + t)]);
       } else {
-      s16x2 m2 = w[0];
-#pragma unroll
-      for (int j = 1; j < 16; ++j) m2 = __builtin_elementwise_max(m2, w[j]);
-      const int m = max1632_i(max((int)m2.x, (int)m2.y));
-      const s16x2 mm = {(short)m, (short)m};
-      const s16x2 cap = {15, 15};                  // 256 >> s and inv_hi >> s are both 0 from s = 9 on
-      const u16x2 one = {256, 256};
-      u16x2 sh[16], sum2 = {0, 0};
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        sh[j] = __builtin_bit_cast(u16x2, __builtin_elementwise_min((s16x2)(mm - w[j]), cap));
-        sum2 += one >> sh[j];
-      }
-      int sum = sum1632_i((int)sum2.x + (int)sum2.y);   // <= 16 * 256 per half: no 16-bit overflow
-      sum = max(sum, 1);
-      const int inv_hi = ((int)floorf((1.0f / (float)sum) * 16711680.0f)) >> 8;   // <= 255: sum >= 256
-      const u16x2 iv = {(unsigned short)inv_hi, (unsigned short)inv_hi};
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int kt = 4 * kb + t;
-          const unsigned p01 = __builtin_bit_cast(unsigned, (u16x2)(iv >> sh[2 * kt]));
-          const unsigned p23 = __builtin_bit_cast(unsigned, (u16x2)(iv >> sh[2 * kt + 1]));
-          pf[kb][t] = (int)(__builtin_amdgcn_perm(p23, p01, 0x06040200u) ^ 0x80808080u);
-        }
+        ita_softmax_packed16(w, pf);
       }
       ITA_SSTAMP(4);
       // A.V with uint8 probabilities on a signed MFMA: (p - 128) * v summed + 128 * colsum(v)

@@ -28,13 +28,13 @@ IMAGE_F32, IMAGE_U8 = 0, 1
 DISPATCH_F16, DISPATCH_F32 = 0, 1
 
 EXPORTED_SYMBOLS = (
-    "ita_abi_version", "ita_create", "ita_destroy", "ita_load_weights", "ita_reserve", "ita_get_dims",
+    "ita_abi_version", "ita_create", "ita_destroy", "ita_load_weights", "ita_validate_blob", "ita_reserve", "ita_get_dims",
     "ita_last_error", "ita_error_string", "ita_mha_int8", "ita_mha_int8_taps", "ita_ffn_int8", "ita_ffn_int8_taps",
     "ita_encoder_layer", "ita_tokenizer", "ita_fusion_tail", "ita_vitlstm_forward", "ita_bind_dispatch",
     "ita_profile_begin", "ita_profile_begin_sampled", "ita_profile_end", "ita_set_tail_mode", "ita_debug_encoder_stamps",
     "ita_fusion_tail_load", "ita_fusion_tail_large",
     "ita_wire_unpack_packet", "ita_wire_postprocess", "ita_vitlstm_forward_slots", "ita_vitlstm_front",
-    "ita_vitlstm_back", "ita_vitlstm_front_ev",
+    "ita_vitlstm_back", "ita_vitlstm_front_ev", "ita_vitlstm_tail", "ita_debug_softmax_rows",
     "ITASelfAttention_workgroup", "ITASelfAttention_workgroup_expanded", "ITAFeedForward_workgroup",
 )
 
@@ -116,6 +116,9 @@ def lib():
         L.ita_vitlstm_front.argtypes = [vp, vp, i, i, i, vp]
         L.ita_vitlstm_front_ev.argtypes = [vp, vp, i, i, i, vp, vp]
         L.ita_vitlstm_back.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp]
+        L.ita_vitlstm_tail.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, vp]
+        L.ita_debug_softmax_rows.argtypes = [vp, vp, vp, i, vp]
+        L.ita_validate_blob.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
         L.ita_bind_dispatch.argtypes = [vp, i, i]
         L.ita_wire_unpack_packet.argtypes = [vp, C.c_size_t, i, vp]
         L.ita_wire_postprocess.argtypes = [vp, C.c_float, C.c_float, vp]
@@ -147,8 +150,10 @@ def _torch():
     return torch
 
 
-def _stream_ptr():
-    return C.c_void_p(_torch().cuda.current_stream().cuda_stream)
+def _stream_ptr(device=None):
+    """handle of torch's current stream ON `device` (an Engine passes its own ordinal: the current stream of whatever
+    device happens to be current would belong to another GPU)"""
+    return C.c_void_p(_torch().cuda.current_stream(device).cuda_stream)
 
 
 def _dev_f32(t, shape=None):
@@ -200,14 +205,14 @@ class Engine:
         B = x.shape[0]
         y = torch.empty_like(x)
         if not taps:
-            _chk(lib().ita_mha_int8(self._h, layer, x.data_ptr(), y.data_ptr(), B, _stream_ptr()))
+            _chk(lib().ita_mha_int8(self._h, layer, x.data_ptr(), y.data_ptr(), B, _stream_ptr(self.device)))
             return y
         mk = lambda *s, dt=torch.int8: torch.empty(s, dtype=dt, device=x.device)
         t = dict(x_q=mk(B, 128, self.E), Q=mk(B, 128, self.P), K=mk(B, 128, self.P), V=mk(B, 128, self.P),
                  logits=mk(B, 128, 128), probs=mk(B, 128, 128, dt=torch.uint8), ctx=mk(B, 128, self.P),
                  out_q=mk(B, 128, self.E))
         st = _MhaTaps(**{k: v.data_ptr() for k, v in t.items()})
-        _chk(lib().ita_mha_int8_taps(self._h, layer, x.data_ptr(), y.data_ptr(), B, C.byref(st), _stream_ptr()))
+        _chk(lib().ita_mha_int8_taps(self._h, layer, x.data_ptr(), y.data_ptr(), B, C.byref(st), _stream_ptr(self.device)))
         return y, t
 
     def ffn(self, x, layer: int = 0, taps: bool = False):
@@ -216,18 +221,18 @@ class Engine:
         B = x.shape[0]
         y = torch.empty_like(x)
         if not taps:
-            _chk(lib().ita_ffn_int8(self._h, layer, x.data_ptr(), y.data_ptr(), B, _stream_ptr()))
+            _chk(lib().ita_ffn_int8(self._h, layer, x.data_ptr(), y.data_ptr(), B, _stream_ptr(self.device)))
             return y
         mk = lambda *s: torch.empty(s, dtype=torch.int8, device=x.device)
         t = dict(x_q=mk(B, 128, self.E), h=mk(B, 128, self.F), out_q=mk(B, 128, self.E))
         st = _FfnTaps(**{k: v.data_ptr() for k, v in t.items()})
-        _chk(lib().ita_ffn_int8_taps(self._h, layer, x.data_ptr(), y.data_ptr(), B, C.byref(st), _stream_ptr()))
+        _chk(lib().ita_ffn_int8_taps(self._h, layer, x.data_ptr(), y.data_ptr(), B, C.byref(st), _stream_ptr(self.device)))
         return y, t
 
     def encoder_layer(self, x, layer: int = 0):
         x = _dev_f32(x)
         y = _torch().empty_like(x)
-        _chk(lib().ita_encoder_layer(self._h, layer, x.data_ptr(), y.data_ptr(), x.shape[0], _stream_ptr()))
+        _chk(lib().ita_encoder_layer(self._h, layer, x.data_ptr(), y.data_ptr(), x.shape[0], _stream_ptr(self.device)))
         return y
 
     # ---- float stages ------------------------------------------------------------------
@@ -236,21 +241,25 @@ class Engine:
         img, dt = self._image(img)
         B = img.shape[0]
         tok = torch.empty((B, 128, self.E), dtype=torch.float32, device=img.device)
-        _chk(lib().ita_tokenizer(self._h, img.data_ptr(), dt, tok.data_ptr(), B, _stream_ptr()))
+        _chk(lib().ita_tokenizer(self._h, img.data_ptr(), dt, tok.data_ptr(), B, _stream_ptr(self.device)))
         return tok
 
     def fusion_tail(self, x):
         torch = _torch()
         x = _dev_f32(x)
         feat = torch.empty((x.shape[0], 4608), dtype=torch.float32, device=x.device)
-        _chk(lib().ita_fusion_tail(self._h, x.data_ptr(), feat.data_ptr(), x.shape[0], _stream_ptr()))
+        _chk(lib().ita_fusion_tail(self._h, x.data_ptr(), feat.data_ptr(), x.shape[0], _stream_ptr(self.device)))
         return feat
 
     def _image(self, img):
         torch = _torch()
         if not img.is_cuda:
             raise ITAError("image must be a GPU tensor")
+        if img.device.index != self.device:
+            raise ITAError(f"tensor lives on cuda:{img.device.index}, the engine on cuda:{self.device}")
         if img.dtype == torch.uint8:
+            if tuple(img.shape[-2:]) != (60, 90):   # wire frames are exactly 60 x 90 (ita_wire.h); no silent re-framing
+                raise ITAError(f"u8 wire frames must be (..., 60, 90), got {tuple(img.shape)}")
             img = img.reshape(-1, 60, 90).contiguous()
             return img, IMAGE_U8
         img = img.float()
@@ -283,14 +292,42 @@ class Engine:
         tp, st = {}, None
         if taps:
             mk = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-            tp = dict(tokens=mk(B, 128, self.E), x1=mk(B, 128, self.E), x2=mk(B, 128, self.E), feat=mk(B, 4608),
-                      dec=mk(B, 512))
-            st = C.byref(_FwdTaps(**{k: v.data_ptr() for k, v in tp.items()}))
+            tp = dict(tokens=mk(B, 128, self.E), x1=mk(B, 128, self.E), x2=mk(B, 128, self.E))
+            if getattr(self, "_tail_mode", 1) == 0:   # the folded tail (mode 1) never materialises feat / dec
+                tp.update(feat=mk(B, 4608), dec=mk(B, 512))
+            st = C.byref(_FwdTaps(**{k: tp[k].data_ptr() if k in tp else None for k in ("tokens", "x1", "x2", "feat", "dec")}))
         _chk(lib().ita_vitlstm_forward(self._h, img.data_ptr(), dt, desvel.data_ptr(), quat.data_ptr(),
                                        h_in.data_ptr(), c_in.data_ptr(), vel.data_ptr(), h_out.data_ptr(),
-                                       c_out.data_ptr(), B, st, _stream_ptr()))
+                                       c_out.data_ptr(), B, st, _stream_ptr(self.device)))
         if taps:
             return vel, (h_out, c_out), tp
+        return vel, (h_out, c_out)
+
+    def softmax_rows(self, logits):
+        """IntegerApproximatedSoftmax through the encoder kernel's own device function: int8 (R,128) -> uint8 (R,128)"""
+        torch = _torch()
+        assert logits.dtype == torch.int8 and logits.is_cuda and logits.shape[-1] == 128
+        lg = logits.reshape(-1, 128).contiguous()
+        out = torch.empty(lg.shape, dtype=torch.uint8, device=lg.device)
+        _chk(lib().ita_debug_softmax_rows(self._h, lg.data_ptr(), out.data_ptr(), lg.shape[0], _stream_ptr(self.device)))
+        return out.reshape(logits.shape)
+
+    def tail(self, x2, desvel, quat, hidden=None):
+        """the graph behind the encoder: x2 (B,128,64) -> (vel, (h, c))   (fusion tail, decoder, LSTM, fc)"""
+        torch = _torch()
+        x2 = _dev_f32(x2)
+        B, dev = x2.shape[0], x2.device
+        desvel, quat = _dev_f32(desvel).reshape(B), _dev_f32(quat, (B, 4))
+        if hidden is None:
+            h_in = torch.zeros((3, B, 128), dtype=torch.float32, device=dev)
+            c_in = torch.zeros((3, B, 128), dtype=torch.float32, device=dev)
+        else:
+            h_in, c_in = _dev_f32(hidden[0], (3, B, 128)), _dev_f32(hidden[1], (3, B, 128))
+        vel = torch.empty((B, 3), dtype=torch.float32, device=dev)
+        h_out, c_out = torch.empty_like(h_in), torch.empty_like(c_in)
+        _chk(lib().ita_vitlstm_tail(self._h, x2.data_ptr(), desvel.data_ptr(), quat.data_ptr(), h_in.data_ptr(),
+                                    c_in.data_ptr(), vel.data_ptr(), h_out.data_ptr(), c_out.data_ptr(), B,
+                                    _stream_ptr(self.device)))
         return vel, (h_out, c_out)
 
     def encoder_stamps(self, x, layer: int = 0):
@@ -307,12 +344,13 @@ class Engine:
         st = torch.zeros((nb, 8, 2, 16), dtype=torch.int64, device=x.device)
         _chk(lib().ita_debug_encoder_stamps(self._h, layer, xp.data_ptr() if xp is not None else None,
                                             img.data_ptr() if img is not None else None, y.data_ptr(), B, st.data_ptr(),
-                                            _stream_ptr()))
+                                            _stream_ptr(self.device)))
         return st
 
     def set_tail_mode(self, mode: int):
         """1: folded conv+decoder, f16x3 split-precision MFMA tail (default); 0: exact f32 kernels"""
         _chk(lib().ita_set_tail_mode(self._h, mode))
+        self._tail_mode = mode
 
     # ---- per-stage device timing ---------------------------------------------------------
     STAGES = ("tokenizer", "mha", "ffn", "tail", "decoder", "lstm_fc")
@@ -334,7 +372,7 @@ class Engine:
         encoder_done: optional torch.cuda.Event (already recorded once, so that its handle exists) recorded between
         the encoder and the GEMM"""
         img, dt = self._image(img)
-        sp = _stream_ptr() if stream is None else C.c_void_p(stream.cuda_stream)
+        sp = _stream_ptr(self.device) if stream is None else C.c_void_p(stream.cuda_stream)
         ev = None if encoder_done is None else C.c_void_p(encoder_done.cuda_event)
         _chk(lib().ita_vitlstm_front_ev(self._h, img.data_ptr(), dt, img.shape[0], buf, sp, ev))
         return img.shape[0]
@@ -342,7 +380,7 @@ class Engine:
     def back(self, desvel, quat, hidden, out, buf: int, stream=None):
         """state half of a time step (LSTM + fc) from buffer `buf`; out = (vel, h_out, c_out) tensors"""
         B = out[0].shape[0]
-        sp = _stream_ptr() if stream is None else C.c_void_p(stream.cuda_stream)
+        sp = _stream_ptr(self.device) if stream is None else C.c_void_p(stream.cuda_stream)
         _chk(lib().ita_vitlstm_back(self._h, desvel.data_ptr(), quat.data_ptr(), hidden[0].data_ptr(),
                                     hidden[1].data_ptr(), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), B,
                                     buf, sp))
@@ -359,7 +397,7 @@ class Engine:
         vel = torch.empty((B, 3), dtype=torch.float32, device=img.device)
         _chk(lib().ita_vitlstm_forward_slots(self._h, img.data_ptr(), dt, desvel.data_ptr(), quat.data_ptr(),
                                              state_h.data_ptr(), state_c.data_ptr(), slot_idx.data_ptr(),
-                                             state_h.shape[1], vel.data_ptr(), B, _stream_ptr()))
+                                             state_h.shape[1], vel.data_ptr(), B, _stream_ptr(self.device)))
         return vel
 
     def graphed_step(self, batch: int) -> "GraphedStep":
@@ -441,7 +479,7 @@ class FusionTailLarge:
             raise ITAError(f"x must be (B, {tok_h * tok_w}, {self.E})")
         if out is None:
             out = torch.empty((B, self.CO, 2 * tok_h, 2 * tok_w), dtype=torch.float32, device=x.device)
-        _chk(lib().ita_fusion_tail_large(self._h, x.data_ptr(), out.data_ptr(), B, tok_h, tok_w, _stream_ptr()))
+        _chk(lib().ita_fusion_tail_large(self._h, x.data_ptr(), out.data_ptr(), B, tok_h, tok_w, _stream_ptr(self.device)))
         return out
 
     def close(self):

@@ -51,8 +51,19 @@ int ita_destroy(ita_handle h);
  * The reference pre-loads weights into the accelerator out of band
  * (docs/HOW-TO-run-the-full-project-workflow.md:55); this is that step. */
 int ita_load_weights(ita_handle h, const void* blob, size_t nbytes);
-/* Pre-sizes the internal workspace for batches up to max_batch so that the compute calls below
- * allocate nothing.  (They grow it on demand otherwise.) */
+/* The structural check ita_load_weights runs first (ita_weights.h: ita_blob_validate): header, table bounds, and the exact
+ * dtype / byte size of every tensor the loader knows, derived from E / P / F / num_layers.  Host only, needs no GPU.
+ * bad_name32 (char[32], may be NULL) receives the offending tensor's name. */
+int ita_validate_blob(const void* blob, size_t nbytes, char* bad_name32);
+/* Pre-sizes the internal workspace for batches up to max_batch so that the compute calls below allocate nothing, and
+ * PINS it: after ita_reserve a larger batch is an error (ITA_ERR_INVALID_ARG) instead of a silent reallocation -- HIP
+ * graphs captured over this handle and ita_vitlstm_front / _back pairs hold raw pointers into the workspace.  Call
+ * ita_reserve again (it synchronises the device) to move to a larger size.  Without any ita_reserve the compute calls
+ * grow the workspace on demand (an implicit device synchronisation; refused inside a stream capture).
+ *
+ * Concurrency: a handle owns ONE workspace and one set of profiling state -- at most one call may be in flight per
+ * handle at a time, on one stream (calls on the same stream are ordered and safe).  Use one handle per stream or per
+ * thread; the weights are small (about 25 MB with the derived buffers). */
 int ita_reserve(ita_handle h, int max_batch);
 int ita_get_dims(ita_handle h, int* E, int* S, int* P, int* F, int* H, int* num_layers);
 
@@ -104,6 +115,12 @@ int ita_vitlstm_forward(ita_handle h, const void* image_dev, int image_dtype, co
                         const float* quat_data_dev, const float* hidden_in_h_dev, const float* hidden_in_c_dev,
                         float* output_dev, float* hidden_out_h_dev, float* hidden_out_c_dev, int batch,
                         const ita_forward_taps* taps, void* stream);
+
+/* The part of the graph behind the encoder on its own (QAT/model.py:116-130): x2 (B,128,64) f32 = the last LayerNorm2
+ * output -> fusion tail -> decoder -> cat -> 3 LSTM layers -> fc, in the arithmetic ita_set_tail_mode selects. */
+int ita_vitlstm_tail(ita_handle h, const float* x2_dev, const float* additional_data_dev, const float* quat_data_dev,
+                     const float* hidden_in_h_dev, const float* hidden_in_c_dev, float* output_dev,
+                     float* hidden_out_h_dev, float* hidden_out_c_dev, int batch, void* stream);
 
 /* The same graph cut in two, for software pipelining ACROSS time steps.  A time step's image-only part
  * (tokenizer, encoder, folded tail GEMM) does not depend on the LSTM state, so step t+1's front can run on
@@ -176,6 +193,11 @@ int ita_fusion_tail_large(ita_handle h, const float* x_dev, float* out_dev, int 
  * and conv + LayerNorm of the NEXT frame.  Not used by the product path. */
 int ita_debug_encoder_stamps(ita_handle h, int layer, const float* x_dev, const void* image_u8_dev, float* y_dev,
                              int batch, unsigned long long* stamps_dev, void* stream);
+
+/* Diagnostic / test entry: IntegerApproximatedSoftmax (models/ITA/QAT/ITA_softmax.py:51-61) alone, through the same
+ * device function and register layout the encoder kernel uses between QK^T and A.V: int8 logits (rows,128) -> u8
+ * probabilities (rows,128), both device pointers.  Needs no weights. */
+int ita_debug_softmax_rows(ita_handle h, const int8_t* logits_dev, uint8_t* probs_dev, int rows, void* stream);
 
 /* ---- wire format of the reference's UDP host (ita_wire.h), exported for bindings and tests ------- */
 /* frame_out: [desired_velocity, position_x, quat w, x, y, z]; returns 0, or -1 on a short packet */

@@ -82,6 +82,75 @@ static inline const void* ita_blob_data(const void* blob, const ita_blob_entry* 
   return e ? (const void*)((const char*)blob + e->offset) : NULL;
 }
 
+/* Structural validation of a whole blob BEFORE anything dereferences a tensor: header, table bounds, 16-byte
+ * alignment, and for every tensor name the loader knows its exact dtype and byte size as derived from
+ * E / P / F / num_layers (a truncated or wrong-E tensor would otherwise be read past its end on the host and on
+ * the device).  Required: the int8 block tensors of every layer; everything else is optional but, when present,
+ * must have the right size.  Unknown names are ignored.  Returns 0, or a negative code and the offending tensor
+ * name in bad_name[32] (may be NULL):  -1 header / table, -2 a required tensor is missing, -3 wrong dtype or size. */
+static inline int ita_blob_validate(const void* blob, size_t nbytes, char* bad_name) {
+  if (bad_name) bad_name[0] = 0;
+  if (!blob || nbytes < sizeof(ita_blob_header)) return -1;
+  const ita_blob_header* h = (const ita_blob_header*)blob;
+  if (memcmp(h->magic, ITA_BLOB_MAGIC, 8) != 0) return -1;
+  if (h->n_tensors < 0 || sizeof(ita_blob_header) + (size_t)h->n_tensors * sizeof(ita_blob_entry) > nbytes) return -1;
+  if (h->E <= 0 || h->E % 64 || h->E > 1024 || h->S != 128 || h->P <= 0 || h->P % 64 || h->F <= 0 || h->F % 64 || h->H != 1 ||
+      h->num_layers < 1 || h->num_layers > 16)
+    return -1;
+  const ita_blob_entry* e = (const ita_blob_entry*)((const char*)blob + sizeof(ita_blob_header));
+  for (int i = 0; i < h->n_tensors; ++i) {
+    if (e[i].offset < 0 || e[i].nbytes < 0 || (size_t)e[i].offset > nbytes || (size_t)e[i].nbytes > nbytes - (size_t)e[i].offset ||
+        (e[i].offset & 15)) {
+      if (bad_name) { memcpy(bad_name, e[i].name, 31); bad_name[31] = 0; }
+      return -1;
+    }
+  }
+  const size_t E = (size_t)h->E, P = (size_t)h->P, F = (size_t)h->F, CIN = E / 4 + E;
+  struct spec { const char* fmt; int dtype; size_t nbytes; int required; int per_layer; };
+  const size_t dec_k = h->has_tail ? 4608 : (size_t)h->S * E;   /* decoder input: fusion-tail map, or the flattened tokens */
+  const struct spec specs[] = {
+    {"attn%d.wq", ITA_I8, P * E, 1, 1}, {"attn%d.wk", ITA_I8, P * E, 1, 1}, {"attn%d.wv", ITA_I8, P * E, 1, 1},
+    {"attn%d.wo", ITA_I8, E * P, 1, 1}, {"attn%d.bq", ITA_I32, P * 4, 1, 1}, {"attn%d.bk", ITA_I32, P * 4, 1, 1},
+    {"attn%d.bv", ITA_I32, P * 4, 1, 1}, {"attn%d.bo", ITA_I32, E * 4, 1, 1}, {"attn%d.scal", ITA_F32, ITA_A_NSCAL * 4, 1, 1},
+    {"ffn%d.w1", ITA_I8, F * E, 1, 1}, {"ffn%d.w2", ITA_I8, E * F, 1, 1}, {"ffn%d.b1", ITA_I32, F * 4, 1, 1},
+    {"ffn%d.b2", ITA_I32, E * 4, 1, 1}, {"ffn%d.scal", ITA_F32, ITA_F_NSCAL * 4, 1, 1},
+    {"norm1_%d.w", ITA_F32, E * 4, 0, 1}, {"norm1_%d.b", ITA_F32, E * 4, 0, 1}, {"norm2_%d.w", ITA_F32, E * 4, 0, 1},
+    {"norm2_%d.b", ITA_F32, E * 4, 0, 1},
+    {"tok.conv_w", ITA_F32, E * 49 * 4, 0, 0}, {"tok.conv_b", ITA_F32, E * 4, 0, 0}, {"tok.ln_w", ITA_F32, E * 4, 0, 0},
+    {"tok.ln_b", ITA_F32, E * 4, 0, 0}, {"tail.conv_w", ITA_F32, 9 * CIN * 9 * 4, 0, 0}, {"tail.conv_b", ITA_F32, 9 * 4, 0, 0},
+    {"dec.w", ITA_F32, 512 * dec_k * 4, 0, 0}, {"dec.b", ITA_F32, 512 * 4, 0, 0},
+    {"lstm.w_ih0", ITA_F32, 512 * 517 * 4, 0, 0}, {"lstm.w_ih1", ITA_F32, 512 * 128 * 4, 0, 0}, {"lstm.w_ih2", ITA_F32, 512 * 128 * 4, 0, 0},
+    {"lstm.w_hh0", ITA_F32, 512 * 128 * 4, 0, 0}, {"lstm.w_hh1", ITA_F32, 512 * 128 * 4, 0, 0}, {"lstm.w_hh2", ITA_F32, 512 * 128 * 4, 0, 0},
+    {"lstm.b_ih0", ITA_F32, 512 * 4, 0, 0}, {"lstm.b_ih1", ITA_F32, 512 * 4, 0, 0}, {"lstm.b_ih2", ITA_F32, 512 * 4, 0, 0},
+    {"lstm.b_hh0", ITA_F32, 512 * 4, 0, 0}, {"lstm.b_hh1", ITA_F32, 512 * 4, 0, 0}, {"lstm.b_hh2", ITA_F32, 512 * 4, 0, 0},
+    {"fc.w", ITA_F32, 3 * 128 * 4, 0, 0}, {"fc.b", ITA_F32, 3 * 4, 0, 0},
+  };
+  for (size_t s = 0; s < sizeof(specs) / sizeof(specs[0]); ++s) {
+    const int reps = specs[s].per_layer ? h->num_layers : 1;
+    for (int l = 0; l < reps; ++l) {
+      char nm[32];
+      int k = 0;   /* tiny formatter: the only conversion is one %d */
+      for (const char* f = specs[s].fmt; *f && k < 30; ++f) {
+        if (f[0] == '%' && f[1] == 'd') {
+          if (l >= 10) nm[k++] = (char)('0' + l / 10);
+          nm[k++] = (char)('0' + l % 10);
+          ++f;
+        } else {
+          nm[k++] = *f;
+        }
+      }
+      nm[k] = 0;
+      const ita_blob_entry* t = ita_blob_find(blob, nbytes, nm);
+      if (!t) {
+        if (specs[s].required) { if (bad_name) strcpy(bad_name, nm); return -2; }
+        continue;
+      }
+      if (t->dtype != specs[s].dtype || (size_t)t->nbytes != specs[s].nbytes) { if (bad_name) strcpy(bad_name, nm); return -3; }
+    }
+  }
+  return 0;
+}
+
 #ifdef __cplusplus
 }
 #endif

@@ -156,6 +156,32 @@ def linear_f32(x, w, b):
     return y
 
 
+def lstm_cell(x, w_ih, w_hh, b_ih, b_hh, h_in, c_in):
+    """one nn.LSTM layer, seq_len 1 (QAT/model.py:128-129): x (B,In), h_in/c_in (B,128) -> (h, c)"""
+    x, h_in, c_in = _c(x, np.float32), _c(h_in, np.float32), _c(c_in, np.float32)
+    B, In = x.shape
+    h, c = np.empty((B, 128), np.float32), np.empty((B, 128), np.float32)
+    lib().ita_oracle_lstm_cell(_p(x), B, In, _p(_c(w_ih, np.float32)), _p(_c(w_hh, np.float32)), _p(_c(b_ih, np.float32)),
+                               _p(_c(b_hh, np.float32)), _p(h_in), _p(c_in), _p(h), _p(c))
+    return h, c
+
+
+def head_from_dec(dec, desvel, quat, fp, h_in=None, c_in=None):
+    """the recurrent head after the decoder (QAT/model.py:126-130): cat([dec, desvel/10, quat]) -> 3 LSTM layers ->
+    fc.  fp: float parameters under the reference's state_dict names.  Returns (vel, h (3,B,128), c)."""
+    dec = _c(dec, np.float32)
+    B = dec.shape[0]
+    cat = np.concatenate([dec, (_c(desvel, np.float32).reshape(B, 1) / np.float32(10.0)), _c(quat, np.float32).reshape(B, 4)], 1)
+    h_in = np.zeros((3, B, 128), np.float32) if h_in is None else _c(h_in, np.float32)
+    c_in = np.zeros((3, B, 128), np.float32) if c_in is None else _c(c_in, np.float32)
+    h, c, x = np.empty_like(h_in), np.empty_like(c_in), cat
+    for l in range(3):
+        h[l], c[l] = lstm_cell(x, fp[f"lstm.weight_ih_l{l}"], fp[f"lstm.weight_hh_l{l}"], fp[f"lstm.bias_ih_l{l}"],
+                               fp[f"lstm.bias_hh_l{l}"], h_in[l], c_in[l])
+        x = h[l]
+    return linear_f32(x, fp["nn_fc2.weight"], fp["nn_fc2.bias"]), h, c
+
+
 def forward(blob: bytes, image, desvel, quat, h_in=None, c_in=None, taps=False):
     """module.main_graph semantics with leading batch (QAT/model.py:93-132)."""
     image = np.ascontiguousarray(image)

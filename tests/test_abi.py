@@ -78,3 +78,55 @@ def test_host_refuses_cpu_tensors(so):
         pytest.skip("GPU present")
     with pytest.raises(host.ITAError):
         host.Engine(b"ITAW0001" + b"\0" * 100)
+
+
+def _retable(blob: bytes, edit):
+    """the blob with its tensor table passed through edit(name, entry-dict) -> entry-dict or None (drop)"""
+    n = int(np.frombuffer(blob[8:12], np.int32)[0])
+    ent = np.dtype([("name", "S32"), ("dtype", "<i4"), ("ndim", "<i4"), ("shape", "<i4", 4), ("off", "<i8"), ("nbytes", "<i8")])
+    tab = np.frombuffer(blob[64:64 + n * 72], ent).copy()
+    for t in tab:
+        edit(t["name"].decode(), t)
+    return blob[:64] + tab.tobytes() + blob[64 + n * 72:]
+
+
+def test_blob_validator_rejects_missized_tensors(so):
+    """every tensor the loader knows is checked against (dtype, nbytes) derived from E/P/F/num_layers BEFORE
+    anything dereferences it -- a truncated or wrong-E tensor used to be read past its end on host and device."""
+    lib = host.lib()
+    lib.ita_validate_blob.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+    d = params.load_fixture(golden_files("vitlstm_E64_seed0_B2.npz")[0])
+    blob = params.blob_from_record(d, synth.float_params(0), E=64)
+    bad = ctypes.create_string_buffer(32)
+    assert lib.ita_validate_blob(blob, len(blob), bad) == 0
+    # each of these tensors was accepted at any size by the round-1 loader
+    for name in ("attn0.wk", "attn0.bv", "ffn0.b1", "tok.conv_w", "tok.ln_b", "norm1_0.w", "norm2_0.b", "tail.conv_w",
+                 "dec.w", "lstm.w_ih0", "lstm.w_hh2", "lstm.b_ih1", "fc.w", "fc.b", "attn0.scal"):
+        def shrink(nm, t, name=name):
+            if nm == name:
+                t["nbytes"] -= 16
+        b2 = _retable(blob, shrink)
+        assert lib.ita_validate_blob(b2, len(b2), bad) == -2 and bad.value.decode() == name, name
+        assert lib.ita_last_error() == -2
+    def retype(nm, t):
+        if nm == "attn0.wq":
+            t["dtype"] = 0
+    b3 = _retable(blob, retype)
+    assert lib.ita_validate_blob(b3, len(b3), bad) == -2 and bad.value == b"attn0.wq"
+    def rename(nm, t):
+        if nm == "ffn0.w2":
+            t["name"] = b"ffn0.zz"
+    b4 = _retable(blob, rename)
+    assert lib.ita_validate_blob(b4, len(b4), bad) == -2 and bad.value == b"ffn0.w2"      # required tensor missing
+    def oob(nm, t):
+        if nm == "fc.w":
+            t["off"] = len(blob) - 64
+    b5 = _retable(blob, oob)
+    assert lib.ita_validate_blob(b5, len(b5), bad) == -2
+    # a blob of another embedding width with this header's E: every E-dependent size is off
+    d128 = params.load_fixture(golden_files("blocks_E128_seed0_B1.npz")[0])
+    blob128 = params.blob_from_record(d128, None, E=128)
+    assert lib.ita_validate_blob(blob128, len(blob128), bad) == 0
+    wrong = blob128[:12] + np.int32(64).tobytes() + blob128[16:]
+    assert lib.ita_validate_blob(wrong, len(wrong), bad) == -2
+    assert lib.ita_validate_blob(blob[:100], 100, bad) == -2 and lib.ita_validate_blob(b"", 0, bad) == -2

@@ -175,3 +175,29 @@ def test_violations_are_reported():
         onnx_shim.parse_model(b"\x0a\xff\xff")                        # truncated field
     with pytest.raises(onnx_shim.OnnxShimError, match="no graph"):
         onnx_shim.parse_model(_iv(1, 8))
+
+
+@pytest.mark.gpu
+def test_shim_blob_runs_on_the_engine_and_equals_oracle(oracle):
+    """row n3 end to end: marker-op ONNX bytes -> onnx_shim -> float half of the blob (+ the int8 record of a converted
+    checkpoint) -> Engine.forward on the GPU, against oracle.forward on a blob packed from the ORIGINAL parameters.
+    (The ONNX bytes come from this test's own writer: a real export cannot be produced here -- `onnx` is not in the
+    image -- so parity with the reference exporter's file stays unpinned.)"""
+    import torch
+    from drone_oa_iree_vit_accelerator_amd import host
+    fp = synth.float_params(2, E=64)
+    fx = params.load_fixture(os.path.join(os.path.dirname(__file__), "golden", "vitlstm_E64_seed2_B2.npz"))
+    info = onnx_shim.match_itavitlstm(onnx_shim.parse_model(build_marker_onnx(fp, raw=False)))
+    blob = params.blob_from_record(fx, info["float_params"], E=64)
+    ref_blob = params.blob_from_record(fx, fp, E=64)
+    eng = host.Engine(blob, device=0)
+    cu = lambda a: torch.from_numpy(a).cuda()
+    vel, (h, c), tp = eng.forward(cu(fx["in0.img_u8"]), cu(fx["in0.desvel"]), cu(fx["in0.quat"]), taps=True)
+    ovel, oh, oc, otp = oracle.forward(ref_blob, fx["in0.img_u8"], fx["in0.desvel"], fx["in0.quat"], taps=True)
+    for k in ("tokens", "x1", "x2"):
+        np.testing.assert_array_equal(tp[k].cpu().numpy(), otp[k], err_msg=k)
+    np.testing.assert_allclose(vel.cpu().numpy(), ovel, atol=2e-5, rtol=0)
+    np.testing.assert_allclose(h.cpu().numpy(), oh, atol=2e-5, rtol=0)
+    np.testing.assert_allclose(c.cpu().numpy(), oc, atol=2e-5, rtol=0)
+    np.testing.assert_allclose(vel.cpu().numpy(), fx["s0.vel"], atol=5e-4, rtol=0)     # and the reference fixture
+    eng.close()

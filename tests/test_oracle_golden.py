@@ -150,6 +150,22 @@ def test_float_stages(oracle, path):
 
 
 @pytest.mark.parametrize("path", FIX_VIT, ids=_ids(FIX_VIT))
+def test_lstm_head_from_fixture_decoder(oracle, path):
+    """The recurrent head on its own: the reference's decoder output in, its (h, c) and velocity out, both time steps.
+    No int8 stage sits between input and output here, so the bound is the float one (observed 3e-7): this is what pins
+    the oracle's LSTM / fc restatement, which the end-to-end test only sees through a 5e-4 tolerance."""
+    d = params.load_fixture(path)
+    fp = synth.float_params(int(d["meta.seed"]), E=64)
+    vel, h, c = oracle.head_from_dec(d["s0.dec"], d["in0.desvel"], d["in0.quat"], fp)
+    for got, key in ((vel, "s0.vel"), (h, "s0.h"), (c, "s0.c")):
+        np.testing.assert_allclose(got, d[key], atol=1e-6, rtol=0, err_msg=key)
+    if "s1.dec" in d:
+        vel1, h1, c1 = oracle.head_from_dec(d["s1.dec"], d["in1.desvel"], d["in1.quat"], fp, d["s0.h"], d["s0.c"])
+        for got, key in ((vel1, "s1.vel"), (h1, "s1.h"), (c1, "s1.c")):
+            np.testing.assert_allclose(got, d[key], atol=1e-6, rtol=0, err_msg=key)
+
+
+@pytest.mark.parametrize("path", FIX_VIT, ids=_ids(FIX_VIT))
 def test_full_forward_two_steps(oracle, path):
     """module.main_graph twice, carrying (h, c) like the reference host.  The int8 blocks sit
     behind float LayerNorms, so a 1e-7 float difference can flip an int8 code; the end-to-end

@@ -119,3 +119,28 @@ def test_replay_equals_sequential_walk(tmp_path):
     s = replay.summarize(res)
     assert s["_all"]["frames"] == 11 and set(s) == {"traj_00", "traj_01", "traj_02", "_all"}
     eng.close()
+
+
+@pytest.mark.gpu
+def test_replay_trajectory_equals_oracle(tmp_path, oracle):
+    """row n2 against the ORACLE (round 1 only compared HIP with HIP): every frame of a replayed trajectory, with the
+    state the CPU oracle carries through the same schedule (zero state at the trajectory start, desvel / 10 on the host
+    as main.cpp:155 does), within the float-tail tolerance; the int8 path behind it is bit-exact, so the tokens are equal."""
+    import torch
+    root, meta = _make_root(tmp_path, n_traj=2, lens=(4, 3), seed=11)
+    fx = params.load_fixture(os.path.join(os.path.dirname(__file__), "golden", "vitlstm_E64_seed0_B2.npz"))
+    blob = params.blob_from_record(fx, synth.float_params(0, E=64), E=64)
+    eng = host.Engine(blob, device=0)
+    res = replay.replay(eng, str(root))
+    i = 0
+    for name in sorted(meta):
+        h = c = None
+        rows = replay.load_rows(str(root / name / "data.csv"))
+        for (fname, img, dv, q, gt) in meta[name]:
+            tel = replay.load_telemetry(rows, fname[:-4])
+            ov, h, c = oracle.forward(blob, img[None], np.float32([tel.desired_velocity / 10.0]),
+                                      np.float32([tel.quaternion]), h, c)
+            np.testing.assert_allclose(res[i].output, ov[0], atol=2e-5, rtol=0, err_msg=f"{name}/{fname}")
+            i += 1
+    assert i == len(res)
+    eng.close()
