@@ -235,9 +235,17 @@ ItaMhaArgs mha_args(ita_context* c, int layer, const float* x, float* y, int B, 
   return a;
 }
 
+struct StreamIo;
+int launch_stream(ita_context* c, int layer, int mode, bool fuse_ln, const StreamIo& io, int B, hipStream_t s);
+int launch_mha_stream(ita_context* c, int layer, const float* x, float* y, int B, bool fuse, hipStream_t s);
+
+// the attention block: without taps on the stream kernel (weights resident in LDS, activations chained through
+// registers); with taps, or for a layer without an LDS image, on the tile-phased kernel that can expose every tensor
 int launch_mha(ita_context* c, int layer, const float* x, float* y, int B, bool fuse, const ita_mha_taps* t,
                hipStream_t s) {
   if (fuse && !c->layers[layer].n1w) return fail(ITA_ERR_BAD_BLOB, "norm1 parameters missing from the blob");
+  static const bool block_only = getenv("ITA_MHA_BLOCK_KERNEL") != nullptr;   // A/B switch
+  if (!t && c->layers[layer].simg_mha && !block_only) return launch_mha_stream(c, layer, x, y, B, fuse, s);
   const ItaMhaArgs a = mha_args(c, layer, x, y, B, fuse, t);
   const int grid = B < c->num_cus ? B : c->num_cus;
   if (c->hdr.E == 64) {
@@ -405,6 +413,12 @@ int launch_stream(ita_context* c, int layer, int mode, bool fuse_ln, const Strea
   }
   HIPCHK(hipGetLastError());
   return ITA_OK;
+}
+
+int launch_mha_stream(ita_context* c, int layer, const float* x, float* y, int B, bool fuse, hipStream_t s) {
+  StreamIo io;
+  io.x = x; io.y = y;
+  return launch_stream(c, layer, 1, fuse, io, B, s);
 }
 
 // One encoder layer: the stream kernel (ita_stream_kernel.h) when the layer has an LDS image -- E = 64 and every

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keep it (and what derives from it) in SGPRs
-  const int qi = lane & 15, kq = lane >> 4, token = wave * 16 + qi;   // (the handful of LDS bases derived from these stay hoisted)
+  const int qi0 = lane & 15, kq0 = lane >> 4;   // E = 64: the handful of LDS bases derived from these stay hoisted
   const int* bias = (const int*)(lds + L::BIAS);
   const int *l_bq = bias, *l_bk = bias + P, *l_bo = bias + 3 * P, *l_b1 = bias + 3 * P + E,
             *l_b2 = bias + 3 * P + E + F;
@@ -494,6 +494,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int b = blockIdx.x; b < a.B; b += gridDim.x, ++fi) {
     int ol = lane;
     asm volatile("" : "+v"(ol));   // see the tokenizer above: its per-lane values are re-derived each frame
+    // E = 128 holds twice the activations in registers: there the LDS bases are re-derived per frame as well
+    const int qi = E > 64 ? (ol & 15) : qi0, kq = E > 64 ? (ol >> 4) : kq0, token = wave * 16 + qi;
     const int nb = b + gridDim.x;
     const bool more = nb < a.B;   // (uniform) the next frame exists: its tokenizer pieces run between this frame's phases
     int* cs = colsum + (fi & 1) * P;

@@ -52,15 +52,23 @@ def init(backend: Optional[str] = None, device_index: Optional[int] = None):
 class VelocityGather:
     """Double-buffered asynchronous all-gather of per-rank (frames, 3) velocity tensors.
 
-    All ranks must hold the same number of frames (bench.py: fixed frames per GPU).  `start`
-    issues the collective for this step and returns immediately; `result` waits for it."""
+    Equal shards (`frames_per_rank` on every rank: bench.py's weak-scaling form) or, with `total`, the uneven
+    contiguous shards of shard_range(total, rank, world) (strong scaling: a global batch cut over the ranks): every
+    rank then sends max-shard rows (its tail rows are padding) and `result` returns the `total` valid rows in stream
+    order.  `start` issues the collective for this step and returns immediately; `result` waits for it."""
 
-    def __init__(self, frames_per_rank: int, world: int, device, dtype=None):
+    def __init__(self, frames_per_rank: int, world: int, device, dtype=None, total: Optional[int] = None):
         import torch
         self.world = world
-        self.n = frames_per_rank
         dtype = dtype or torch.float32
-        self.bufs = [torch.empty((world * frames_per_rank, 3), dtype=dtype, device=device) for _ in range(2)]
+        if total is None:
+            self.sizes = [frames_per_rank] * world
+        else:
+            self.sizes = [hi - lo for lo, hi in (shard_range(total, r, world) for r in range(world))]
+        self.n = max(self.sizes) if self.sizes else 0
+        self.even = all(sz == self.n for sz in self.sizes)
+        self.bufs = [torch.empty((world * self.n, 3), dtype=dtype, device=device) for _ in range(2)]
+        self.pad = None if self.even else [torch.zeros((self.n, 3), dtype=dtype, device=device) for _ in range(2)]
         self.handles = [None, None]
         self.i = 0
 
@@ -76,6 +84,11 @@ class VelocityGather:
         i = self.i
         if self.handles[i] is not None:       # buffer about to be reused: its collective must be done
             self.handles[i].wait()
+        if vel.shape[0] != self.n:            # a short shard: send it padded to the longest one
+            if self.pad is None or vel.shape[0] > self.n:
+                raise ValueError(f"velocity tensor has {vel.shape[0]} rows, the gather was built for {self.sizes}")
+            self.pad[i][:vel.shape[0]].copy_(vel)
+            vel = self.pad[i]
         if self.world == 1:
             self.bufs[i].copy_(vel)
             self.handles[i] = None
@@ -96,7 +109,10 @@ class VelocityGather:
         if self.handles[i] is not None:
             self.handles[i].wait()
             self.handles[i] = None
-        return self.bufs[i]
+        if self.even:
+            return self.bufs[i]
+        import torch
+        return torch.cat([self.bufs[i][r * self.n:r * self.n + sz] for r, sz in enumerate(self.sizes)], 0)
 
     def finish(self):
         for i in (0, 1):

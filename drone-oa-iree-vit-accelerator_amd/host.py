@@ -405,6 +405,10 @@ class Engine:
         _chk(lib().ita_reserve(self._h, batch))
         return GraphedStep(self, batch)
 
+    def pipelined_steps(self, batch: int, n_steps: int = 8) -> "PipelinedSteps":
+        """n_steps time steps per HIP-graph replay, front(t+1) overlapping back(t) (see PipelinedSteps)"""
+        return PipelinedSteps(self, batch, n_steps)
+
     # ---- drop-in symbols (host buffers) --------------------------------------------------
     def bind_dispatch(self, layer: int = 0, dtype: int = DISPATCH_F16):
         _chk(lib().ita_bind_dispatch(self._h, layer, dtype))
@@ -443,6 +447,61 @@ class GraphedStep:
 
     def _step(self):
         self.engine.forward(self.img, self.desvel, self.quat, (self.h, self.c), out=(self.vel, self.h, self.c))
+
+    def __call__(self):
+        self.graph.replay()
+        return self.vel
+
+
+class PipelinedSteps:
+    """`n_steps` consecutive time steps captured in ONE HIP graph on two streams: the image-only front of step t+1
+    (tokenizer, encoder, folded GEMM: ita_vitlstm_front) runs while the recurrent back of step t (LSTM layers, fc:
+    ita_vitlstm_back) is still in flight.  The recurrence is respected -- back(t) follows back(t-1) on its stream and
+    front(t) -- and so is the reuse of the two partial-sum buffers (front(t) waits for back(t-2)).  This pays when a GPU
+    holds few streams (up to ~256: the strong-scaling regime of BASELINE config 4 on 8 GPUs): the encoder then leaves CUs
+    free for the small LSTM kernels, and one graph launch replaces 6 * n_steps kernel launches.  At 1024 streams per GPU
+    the encoder owns every CU and nothing overlaps (measured), so bench.py uses this below 256 streams only.
+    Static buffers: `img` (n,B,60,90) u8, `desvel` (n,B), `quat` (n,B,4) in; `vel` (n,B,3) out; `h`, `c` (3,B,128) carried
+    in place from step to step and from replay to replay (zero them to start new streams)."""
+
+    def __init__(self, engine: "Engine", batch: int, n_steps: int = 8):
+        torch = _torch()
+        dev = torch.device("cuda", engine.device)
+        self.engine, self.B, self.n = engine, batch, n_steps
+        _chk(lib().ita_reserve(engine._h, batch))
+        self.img = torch.zeros((n_steps, batch, 60, 90), dtype=torch.uint8, device=dev)
+        self.desvel = torch.zeros((n_steps, batch), dtype=torch.float32, device=dev)
+        self.quat = torch.zeros((n_steps, batch, 4), dtype=torch.float32, device=dev)
+        self.quat[..., 0] = 1
+        self.h = torch.zeros((3, batch, 128), dtype=torch.float32, device=dev)
+        self.c = torch.zeros((3, batch, 128), dtype=torch.float32, device=dev)
+        self.vel = torch.zeros((n_steps, batch, 3), dtype=torch.float32, device=dev)
+        warm = torch.cuda.Stream(device=dev)
+        warm.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(warm):              # outside the capture: kernel attributes, lazy module loads
+            for i in range(2):
+                engine.front(self.img[i], i & 1, stream=warm)
+                engine.back(self.desvel[i], self.quat[i], (self.h, self.c), (self.vel[i], self.h, self.c), i & 1, stream=warm)
+        torch.cuda.current_stream(dev).wait_stream(warm)
+        torch.cuda.synchronize(dev)
+        self.h.zero_()
+        self.c.zero_()
+        self.graph = torch.cuda.CUDAGraph()
+        s_front, s_back = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        ev_front = [torch.cuda.Event() for _ in range(n_steps)]
+        ev_back = [torch.cuda.Event() for _ in range(n_steps)]
+        with torch.cuda.graph(self.graph, stream=s_front):
+            for i in range(n_steps):
+                if i >= 2:
+                    s_front.wait_event(ev_back[i - 2])          # front(i) overwrites the partial buffer back(i-2) read
+                engine.front(self.img[i], i & 1, stream=s_front)
+                ev_front[i].record(s_front)
+                s_back.wait_event(ev_front[i])                  # (also forks s_back into the capture at i = 0)
+                engine.back(self.desvel[i], self.quat[i], (self.h, self.c), (self.vel[i], self.h, self.c), i & 1, stream=s_back)
+                ev_back[i].record(s_back)
+            s_front.wait_stream(s_back)                          # join
+        self.h.zero_()
+        self.c.zero_()
 
     def __call__(self):
         self.graph.replay()

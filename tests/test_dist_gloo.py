@@ -50,7 +50,8 @@ def _worker(rank, world, port, total, steps, q):
     fr = synth.frames(99, total)
     lo, hi = itd.shard_range(total, rank, world)
     n = hi - lo
-    gather = itd.VelocityGather(n, world, torch.device("cpu"))
+    # strong-scaling form: a global batch `total` cut into contiguous shards that may differ by one frame
+    gather = itd.VelocityGather(n, world, torch.device("cpu"), total=total)
     h = np.zeros((3, n, 128), np.float32)
     c = np.zeros((3, n, 128), np.float32)
     outs = []
@@ -68,9 +69,10 @@ def _worker(rank, world, port, total, steps, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gather_matches_single_process(oracle):
+@pytest.mark.parametrize("total", [4, 5], ids=["even_shards", "uneven_shards"])
+def test_two_rank_gather_matches_single_process(oracle, total):
     from drone_oa_iree_vit_accelerator_amd import params, synth
-    total, steps, world = 4, 3, 2
+    steps, world = 3, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

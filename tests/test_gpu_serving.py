@@ -152,3 +152,36 @@ def test_graphed_step_equals_eager_forward():
             assert torch.equal(vg, ve), (B, t)
             assert torch.equal(g.h, st[0]) and torch.equal(g.c, st[1])
     eng.close()
+
+
+@pytest.mark.parametrize("B", [3, 130])
+def test_pipelined_graph_steps_equal_sequential_forward(B):
+    """host.PipelinedSteps: 8 time steps per HIP-graph replay with front(t+1) overlapping back(t) on a second stream must
+    give, step by step and across two replays (state carried), exactly the velocities and the state of 16 sequential
+    ita_vitlstm_forward calls."""
+    import torch
+    fx = params.load_fixture(os.path.join(os.path.dirname(__file__), "golden", "vitlstm_E64_seed0_B2.npz"))
+    eng = host.Engine(params.blob_from_record(fx, synth.float_params(0, E=64), E=64), device=0)
+    n = 8
+    frs = [synth.frames(500 + t, B) for t in range(2 * n)]
+    ps = eng.pipelined_steps(B, n)
+    got = []
+    for rep in range(2):
+        for t in range(n):
+            f = frs[rep * n + t]
+            ps.img[t].copy_(torch.from_numpy(f["img_u8"]))
+            ps.desvel[t].copy_(torch.from_numpy(f["desvel"]).reshape(B))
+            ps.quat[t].copy_(torch.from_numpy(f["quat"]))
+        got.append(ps().clone())
+    torch.cuda.synchronize()
+    h_pipe, c_pipe = ps.h.clone(), ps.c.clone()
+    eng2 = host.Engine(params.blob_from_record(fx, synth.float_params(0, E=64), E=64), device=0)
+    st = None
+    for t in range(2 * n):
+        f = frs[t]
+        v, st = eng2.forward(torch.from_numpy(f["img_u8"]).cuda(), torch.from_numpy(f["desvel"]).cuda(),
+                             torch.from_numpy(f["quat"]).cuda(), st)
+        assert torch.equal(got[t // n][t % n], v), f"step {t}"
+    assert torch.equal(h_pipe, st[0]) and torch.equal(c_pipe, st[1])
+    del ps
+    eng.close(); eng2.close()

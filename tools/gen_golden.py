@@ -309,11 +309,66 @@ def gen_tail_large(out_dir):
         print("wrote", name, tuple(out.shape))
 
 
+def gen_float_twin(seed, B, out_dir):
+    """The reference's FLOAT model (models/ITA_single_layer_upsample_shuffle/model.py:35-140 with the float blocks of
+    models/ITA/layers.py: nn.Softmax attention) -- the graph its CPU .vmfb holds.  decoder and
+    nn_fc2 are declared under spectral_norm (model.py:81,84); the parametrisation is removed on the instance
+    (torch.nn.utils.remove_spectral_norm leaves a plain weight) so that the synthetic weights ARE the effective ones --
+    in eval mode the module then computes exactly F.linear(x, weight, bias).  Two time steps, state carried."""
+    from models.ITA_single_layer_upsample_shuffle.model import ITALSTMNetVIT
+    fp = synth.float_params(seed, E=64)
+    model = ITALSTMNetVIT(num_layers=1)
+    for lin in (model.decoder, model.nn_fc2):
+        torch.nn.utils.remove_spectral_norm(lin)
+        lin._load_state_dict_pre_hooks.clear()   # the removal leaves spectral_norm's load hook behind (it demands weight_orig)
+    sd = model.state_dict()
+    for k, v in fp.items():
+        assert k in sd and tuple(sd[k].shape) == v.shape, k
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in fp.items()}, strict=True)
+    model.eval()
+    tap = Tap()
+    tap.add(model.tokenizer, "tok.out")
+    tap.add(model.norms1[0], "x1")
+    tap.add(model.norms2[0], "x2")
+    tap.add(model.decoder, "dec")
+    fr0, fr1 = synth.frames(10 * seed, B), synth.frames(10 * seed + 1, B)
+    with torch.no_grad():
+        vel0, (h0, c0) = model(to_X(fr0, None))
+        stage = dict(tap.t)
+        vel1, (h1, c1) = model(to_X(fr1, (h0, c0)))
+    rec = {"meta.seed": np.int64(seed), "meta.B": np.int64(B), "meta.params_sha256": np.array(synth.digest(fp)),
+           "meta.torch": np.array(torch.__version__)}
+    for k, v in fr0.items():
+        rec["in0." + k] = v
+    for k, v in fr1.items():
+        rec["in1." + k] = v
+    for k, v in stage.items():
+        rec["s0." + k] = v
+    rec["s0.vel"] = vel0.numpy(); rec["s0.h"] = h0.numpy(); rec["s0.c"] = c0.numpy()
+    rec["s1.vel"] = vel1.numpy(); rec["s1.h"] = h1.numpy(); rec["s1.c"] = c1.numpy()
+    path = os.path.join(out_dir, f"floattwin_E64_s{seed}_B{B}.npz")    # (not "*_seed*": that glob selects the int8 fixtures)
+    np.savez_compressed(path, **rec)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    ap.add_argument("--only", default="", help="comma list of: softmax, vitlstm, blocks, tail_large, float_twin (default: all)")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
+    only = set(filter(None, a.only.split(",")))
+    if only:
+        if "softmax" in only: gen_softmax(a.out)
+        if "vitlstm" in only:
+            for seed in (0, 1, 2): gen_vitlstm(seed, 2, a.out)
+        if "blocks" in only:
+            for seed in (0, 1): gen_blocks(seed, 128, 1, a.out)
+            gen_blocks(2, 64, 1, a.out, gain_qk=6.0)
+        if "tail_large" in only: gen_tail_large(a.out)
+        if "float_twin" in only: gen_float_twin(0, 2, a.out)
+        return
+    gen_float_twin(0, 2, a.out)
     gen_softmax(a.out)
     for seed in (0, 1, 2):
         gen_vitlstm(seed, 2, a.out)
