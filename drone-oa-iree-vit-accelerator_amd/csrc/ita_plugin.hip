@@ -493,12 +493,20 @@ int launch_gemm(const float* A, int lda, const float* W, int ldw, const float* b
 
 template <int NT, int WAVES, int TPS>
 int launch_tail_big_w(const ItaTailBigArgs& a, hipStream_t s) {
-  static bool attr_set = false;
+  // the attribute is per DEVICE: one flag per ordinal (a process-wide flag left the second GPU's context without it)
+  static std::mutex mu;
+  static std::vector<char> attr_set;
   auto kern = ita_tail_big_kernel<NT, WAVES, TPS>;
   constexpr int lds_bytes = ItaTailBigLds<NT, WAVES, TPS>::TOTAL;
-  if (!attr_set) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    attr_set = true;
+  {
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> g(mu);
+    if ((int)attr_set.size() <= dev) attr_set.resize(dev + 1, 0);
+    if (!attr_set[dev]) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+      attr_set[dev] = 1;
+    }
   }
   hipLaunchKernelGGL(kern, dim3(2 * a.TW / 32, 2 * a.TH / (2 * WAVES), a.B), dim3(64 * WAVES), lds_bytes, s, a);
   HIPCHK(hipGetLastError());

@@ -12,7 +12,11 @@
 //   * two matchers: `neg` -> attention block, `abs` -> feed-forward block
 //     (models/ITA/export/ITA_ONNX.py:26,38; the reference only matches `neg`);
 //   * host triple x86_64 (the MI355X box), generic CPU.
-// Not exercised in this repository's tests: iree-compile is not installed in the build image.
+// STATUS: NOT COMPILED, NOT VERIFIED -- iree-compile / mlir-opt are not in the build image, so this file has never been
+// through a parser.  It documents the contract; treat it as a starting point, not as a compile-ready artefact.
+// Shapes: 1x128x128 f32 as in the reference spec (the E = 128 block models); the E = 64 ITAViTLSTM export marks its
+// blocks with x + x on 1x128x64 tensors, which needs the same matchers with that shape (and the reference's own
+// negf matcher cannot match it either: SURVEY.md section 8(b)).  ita_bind_dispatch must be given ITA_DISPATCH_F32.
 
 #ita_host_target = #hal.executable.target<"llvm-cpu", "embedded-elf-x86_64", {
   cpu = "generic", data_layout = "e-m:e-p270:32:32-p271:32:32-p272:64:64-i64:64-i128:128-f80:128-n8:16:32:64-S128",
@@ -41,25 +45,23 @@ module attributes {transform.with_named_sequence} {
       }
       builtin.module {
         // resolved through the runtime's executable import provider (symbol names = C ABI names)
-        func.func private @ITASelfAttention_workgroup(memref<f32>, memref<f32>) attributes {hal.import.bitcode = false}
-        func.func private @ITAFeedForward_workgroup(memref<f32>, memref<f32>) attributes {hal.import.bitcode = false}
+        // (the bindings are passed as the 3-D memrefs they are, exactly like the reference spec does, ITA_spec.mlir:30-48;
+        //  round 1 collapsed them to rank 0 with an empty reassociation, which is not a legal memref.collapse_shape)
+        func.func private @ITASelfAttention_workgroup(memref<1x128x128xf32>, memref<1x128x128xf32>) attributes {hal.import.bitcode = false}
+        func.func private @ITAFeedForward_workgroup(memref<1x128x128xf32>, memref<1x128x128xf32>) attributes {hal.import.bitcode = false}
 
         func.func @ITASelfAttention() {
           %c0 = arith.constant 0 : index
           %in = hal.interface.binding.subspan layout(#ita_layout) binding(0) alignment(64) offset(%c0) : memref<1x128x128xf32>
           %out = hal.interface.binding.subspan layout(#ita_layout) binding(1) alignment(64) offset(%c0) : memref<1x128x128xf32>
-          %in0 = memref.collapse_shape %in [] : memref<1x128x128xf32> into memref<f32>
-          %out0 = memref.collapse_shape %out [] : memref<1x128x128xf32> into memref<f32>
-          func.call @ITASelfAttention_workgroup(%in0, %out0) : (memref<f32>, memref<f32>) -> ()
+          func.call @ITASelfAttention_workgroup(%in, %out) : (memref<1x128x128xf32>, memref<1x128x128xf32>) -> ()
           return
         }
         func.func @ITAFeedForward() {
           %c0 = arith.constant 0 : index
           %in = hal.interface.binding.subspan layout(#ita_layout) binding(0) alignment(64) offset(%c0) : memref<1x128x128xf32>
           %out = hal.interface.binding.subspan layout(#ita_layout) binding(1) alignment(64) offset(%c0) : memref<1x128x128xf32>
-          %in0 = memref.collapse_shape %in [] : memref<1x128x128xf32> into memref<f32>
-          %out0 = memref.collapse_shape %out [] : memref<1x128x128xf32> into memref<f32>
-          func.call @ITAFeedForward_workgroup(%in0, %out0) : (memref<f32>, memref<f32>) -> ()
+          func.call @ITAFeedForward_workgroup(%in, %out) : (memref<1x128x128xf32>, memref<1x128x128xf32>) -> ()
           return
         }
       }

@@ -109,7 +109,10 @@ int main(int argc, char** argv) {
   std::vector<uint8_t> carry(ITA_WIRE_PACKET_BYTES + 16);
   sockaddr_in carry_addr{};
   bool have_carry = false;
-  long served = 0, batches = 0;
+  long served = 0, batches = 0, evicted = 0;
+  std::vector<unsigned long long> last_seen(max_streams, 0);   // logical time of a slot's latest packet (LRU eviction)
+  unsigned long long tick = 0;
+  std::vector<int> reset_slots;                                 // slots handed to a new sender: state must restart at zero
 
   while (max_packets < 0 || served < max_packets) {
     batch.clear();
@@ -140,10 +143,23 @@ int main(int argc, char** argv) {
       const auto key = std::make_pair((uint32_t)from.sin_addr.s_addr, (uint16_t)from.sin_port);
       auto it = slot_of.find(key);
       if (it == slot_of.end()) {
-        if ((int)slot_of.size() >= max_streams) { if (!quiet) fprintf(stderr, "stream table full, dropping\n"); continue; }
-        it = slot_of.emplace(key, (int)slot_of.size()).first;
+        int slot = (int)slot_of.size();
+        if (slot >= max_streams) {
+          // table full: take the slot of the stream that has been silent longest (and is not in this batch);
+          // its LSTM state is zeroed below, like a fresh sender's -- the reference host restarts with zero state too
+          auto victim = slot_of.end();
+          for (auto s2 = slot_of.begin(); s2 != slot_of.end(); ++s2)
+            if (!seen[s2->second] && (victim == slot_of.end() || last_seen[s2->second] < last_seen[victim->second])) victim = s2;
+          if (victim == slot_of.end()) { if (!quiet) fprintf(stderr, "every stream slot is in this batch, dropping\n"); continue; }
+          slot = victim->second;
+          slot_of.erase(victim);
+          reset_slots.push_back(slot);
+          ++evicted;
+        }
+        it = slot_of.emplace(key, slot).first;
       }
       p.slot = it->second;
+      last_seen[p.slot] = ++tick;
       if (seen[p.slot]) {   // second frame of the same stream: it needs the state this batch produces
         memcpy(carry.data(), buf, ITA_WIRE_PACKET_BYTES); carry_addr = from; have_carry = true;
         break;
@@ -151,6 +167,12 @@ int main(int argc, char** argv) {
       seen[p.slot] = 1;
       batch.push_back(p);
     }
+    for (int slot : reset_slots)   // (3, max_streams, 128) state arrays: zero this slot's row in each layer
+      for (int l = 0; l < 3; ++l) {
+        HIPOK(hipMemsetAsync(d_h + ((size_t)l * max_streams + slot) * 128, 0, sizeof(float) * 128, stream));
+        HIPOK(hipMemsetAsync(d_c + ((size_t)l * max_streams + slot) * 128, 0, sizeof(float) * 128, stream));
+      }
+    reset_slots.clear();
     if (batch.empty()) continue;
     const int B = (int)batch.size();
     for (int b = 0; b < B; ++b) {
@@ -176,7 +198,7 @@ int main(int argc, char** argv) {
     served += B;
     ++batches;
   }
-  if (!quiet) printf("ita_udp_server: served %ld packets in %ld batches from %zu streams\n", served, batches, slot_of.size());
+  if (!quiet) printf("ita_udp_server: served %ld packets in %ld batches from %zu streams (%ld evictions)\n", served, batches, slot_of.size(), evicted);
   close(sock);
   ita_destroy(ita);
   return 0;

@@ -185,3 +185,45 @@ def test_pipelined_graph_steps_equal_sequential_forward(B):
     assert torch.equal(h_pipe, st[0]) and torch.equal(c_pipe, st[1])
     del ps
     eng.close(); eng2.close()
+
+
+def test_udp_server_evicts_least_recent_stream(oracle):
+    """--max-streams 2 with three senders: the third sender takes the slot of the sender that has been silent longest and
+    starts from ZERO state (round 1 dropped every sender beyond the table size forever); a returning evicted sender
+    also restarts from zero."""
+    exe = host.build_samples()
+    blob = _blob()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    order = [0, 1, 0, 2, 2, 1]          # sender per packet: 2 evicts 1 (0 spoke more recently); later 1 evicts 0
+    with tempfile.NamedTemporaryFile(suffix=".itaw") as f:
+        f.write(blob); f.flush()
+        srv = subprocess.Popen([exe, "--blob", f.name, "--port", str(port), "--max-packets", str(len(order)),
+                                "--max-streams", "2", "--max-batch", "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        try:
+            assert "listening" in srv.stdout.readline()
+            socks = [socket.socket(socket.AF_INET, socket.SOCK_DGRAM) for _ in range(3)]
+            for sk in socks:
+                sk.settimeout(30)
+            zero = lambda: (np.zeros((3, 1, 128), np.float32), np.zeros((3, 1, 128), np.float32))
+            st = {0: zero(), 1: zero(), 2: zero()}
+            table = []                      # senders holding a slot, least recently seen first
+            for t, i in enumerate(order):
+                if i in table:
+                    table.remove(i)
+                elif len(table) == 2:
+                    st[table.pop(0)] = zero()      # evicted: its state is gone
+                    st[i] = zero()
+                table.append(i)
+                fr = synth.frames(700 + t, 1)
+                dv = np.float32(fr["desvel"][0, 0])
+                socks[i].sendto(_packet(fr["img_u8"][0], float(dv), 10.0, fr["quat"][0]), ("127.0.0.1", port))
+                reply, _ = socks[i].recvfrom(64)
+                vel, h, c = oracle.forward(blob, fr["img_u8"], np.array([[dv / np.float32(10.0)]], np.float32), fr["quat"], *st[i])
+                st[i] = (h, c)
+                np.testing.assert_allclose(np.frombuffer(reply, "<f4"), oracle.final_velocity(vel[0], float(dv), 10.0),
+                                           atol=3e-4, rtol=0, err_msg=f"packet {t} from sender {i}")
+            out, _ = srv.communicate(timeout=60)
+            assert srv.returncode == 0 and "2 evictions" in out, out
+        finally:
+            if srv.poll() is None:
+                srv.kill()
