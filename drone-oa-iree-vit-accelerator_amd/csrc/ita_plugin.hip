@@ -39,8 +39,8 @@ int fail(int code, const std::string& msg) {
 
 constexpr int K0P = 672;    // exact-f32 path: LSTM layer-0 concat width 517 + 128 = 645, padded to a multiple of 32
 constexpr int K0S = 144;    // f16x3 path, LSTM layer 0 remainder: [h_in0 (128) | desvel | quat (4) | 0 pad]
-constexpr int KFOLD = 8192; // 128 tokens x 64 channels feeding the folded tail+decoder matrix
-constexpr int LDFOLD = KFOLD + 64;   // row stride of the x2 / Wfold planes: a power-of-two stride (16 KB) would put
+// K of the folded GEMM = 128 tokens x E channels (8192 for ITAViTLSTM, 16384 for the E = 128 graph without a fusion
+// tail); row stride of the x2 / Wfold planes = K + 64: a power-of-two stride (16 KB) would put
                                      // every row of a K tile on the same L2 channel
 constexpr int NSPLIT = 8;   // split-K of the folded GEMM (1024 x 512 x 8192 -> 256 workgroups)
 
@@ -73,6 +73,7 @@ struct ita_context {
   float* wcat[3] = {nullptr, nullptr, nullptr};
   float* bsum[3] = {nullptr, nullptr, nullptr};
   // split-precision (f16 hi/lo) tail: folded tail+decoder matrix and LSTM weights, pre-scaled
+  int kfold = 8192, ldfold = 8192 + 64;    // K and plane row stride of the folded GEMM (see the constants above)
   int tail_mode = 1;                       // 1: folded f16x3 GEMMs (default), 0: exact f32 kernels
   bool folded = false;
   _Float16 *fold_hi = nullptr, *fold_lo = nullptr;   // [512][LDFOLD]: G0 = W_ih0[:, :512] . Wfold, rows in permuted gate order
@@ -193,8 +194,8 @@ int ensure_workspace(ita_context* c, int B, hipStream_t s = nullptr) {
   HIPCHK(hipMalloc(&c->cat1, sizeof(float) * (size_t)B * 256));
   HIPCHK(hipMalloc(&c->cat2, sizeof(float) * (size_t)B * 256));
   HIPCHK(hipMalloc(&c->gates, sizeof(float) * (size_t)B * 512));
-  HIPCHK(hipMalloc(&c->x2_hi, 2 * (size_t)B * LDFOLD));
-  HIPCHK(hipMalloc(&c->x2_lo, 2 * (size_t)B * LDFOLD));
+  HIPCHK(hipMalloc(&c->x2_hi, 2 * (size_t)B * c->ldfold));
+  HIPCHK(hipMalloc(&c->x2_lo, 2 * (size_t)B * c->ldfold));
   HIPCHK(hipMalloc(&c->c1_hi, 2 * (size_t)B * 256));
   HIPCHK(hipMalloc(&c->c1_lo, 2 * (size_t)B * 256));
   HIPCHK(hipMalloc(&c->c2_hi, 2 * (size_t)B * 256));
@@ -266,7 +267,7 @@ int launch_ffn(ita_context* c, int layer, const float* x, float* y, int B, bool 
   a.inv_sx = L.fscal[ITA_F_INV_SX]; a.m1 = L.fscal[ITA_F_M1]; a.m2 = L.fscal[ITA_F_M2]; a.s2 = L.fscal[ITA_F_S2];
   a.ln_w = L.n2w; a.ln_b = L.n2b; a.B = B; a.fuse_ln = fuse ? 1 : 0;
   if (t) { a.t_xq = t->x_q; a.t_h = t->h; a.t_out = t->out_q; }
-  a.y_hi = y_hi; a.y_lo = y_lo; a.ld_planes = LDFOLD;
+  a.y_hi = y_hi; a.y_lo = y_lo; a.ld_planes = c->ldfold;
   const int grid = B < 2 * c->num_cus ? B : 2 * c->num_cus;
   if (c->hdr.E == 64) {
     hipLaunchKernelGGL(ita_ffn_kernel<64>, dim3(grid), dim3(512), ItaFfnLds<64>::TOTAL, s, a);
@@ -386,7 +387,7 @@ struct StreamIo {
 int launch_stream(ita_context* c, int layer, int mode, bool fuse_ln, const StreamIo& io, int B, hipStream_t s) {
   const Layer& L = c->layers[layer];
   ItaStreamArgs a{};
-  a.x = io.x; a.y = io.y; a.y_hi = io.y_hi; a.y_lo = io.y_lo; a.ld_planes = LDFOLD; a.x1_tap = io.x1_tap;
+  a.x = io.x; a.y = io.y; a.y_hi = io.y_hi; a.y_lo = io.y_lo; a.ld_planes = c->ldfold; a.x1_tap = io.x1_tap;
   a.inv_sx = L.ascal[ITA_A_INV_SX]; a.mq = L.ascal[ITA_A_MQ]; a.mk = L.ascal[ITA_A_MK]; a.mv = L.ascal[ITA_A_MV];
   a.ml = L.ascal[ITA_A_ML]; a.mc = L.ascal[ITA_A_MC]; a.mo = L.ascal[ITA_A_MO]; a.so = L.ascal[ITA_A_SO];
   a.f_inv_sx = L.fscal[ITA_F_INV_SX]; a.m1 = L.fscal[ITA_F_M1]; a.m2 = L.fscal[ITA_F_M2]; a.s2 = L.fscal[ITA_F_S2];
@@ -575,36 +576,49 @@ int launch_tail(ita_context* c, const float* x, float* feat, int ld, int B, hipS
 int launch_gemm(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N,
                 int K, hipStream_t s);
 
-// Folds PixelShuffle/Upsample/concat/conv3x3 and the decoder Linear into Wfold[512][8192] by
-// pushing unit impulses through the exact f32 kernels (bias-free), and dec(tail(0)) as the bias.
+// Folds PixelShuffle/Upsample/concat/conv3x3 and the decoder Linear into Wfold[512][K] (K = 128 E) by pushing unit
+// impulses through the exact f32 kernels (bias-free), and dec(tail(0)) as the bias.  Without a fusion tail
+// (models/ITA/QAT/model.py:80-81: the decoder reads the flattened tokens) Wfold is the decoder matrix itself.
 int build_fold(ita_context* c) {
-  const int CH = 1024;
+  const int CH = 1024, KFOLD = c->kfold, LDFOLD = c->ldfold;
+  const bool has_tail = c->hdr.has_tail != 0;
   float *imp = nullptr, *feat = nullptr, *mt = nullptr, *zero = nullptr;
-  HIPCHK(hipMalloc(&imp, sizeof(float) * (size_t)CH * KFOLD));
+  HIPCHK(hipMalloc(&imp, sizeof(float) * (size_t)(has_tail ? CH : 512) * KFOLD));
   HIPCHK(hipMalloc(&feat, sizeof(float) * (size_t)CH * 4608));
   HIPCHK(hipMalloc(&mt, sizeof(float) * (size_t)KFOLD * 512));
   HIPCHK(hipMalloc(&zero, sizeof(float) * 16));
   HIPCHK(hipMemset(zero, 0, sizeof(float) * 16));
-  const float* real_cb = c->tail_b;
   int rc = ITA_OK;
-  c->tail_b = zero;                       // bias-free pass: column i of Wfold = dec_nobias(tail_nobias(e_i))
-  for (int c0 = 0; c0 < KFOLD && !rc; c0 += CH) {
-    const size_t n = (size_t)CH * KFOLD;
-    hipLaunchKernelGGL(ita_impulse_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, imp, CH, KFOLD, c0);
-    if ((rc = launch_tail(c, imp, feat, 4608, CH, nullptr))) break;
-    rc = launch_gemm(feat, 4608, c->dec_w, 4608, nullptr, mt + (size_t)c0 * 512, 512, CH, 512, 4608, nullptr);
-  }
-  c->tail_b = real_cb;
   std::vector<float> hmt((size_t)KFOLD * 512), hb(512);
-  if (!rc) {
-    // bias' = dec(tail(0)) with the real biases
-    HIPCHK(hipMemset(imp, 0, sizeof(float) * KFOLD));
-    if (!(rc = launch_tail(c, imp, feat, 4608, 1, nullptr)))
-      rc = launch_gemm(feat, 4608, c->dec_w, 4608, c->dec_b, imp, 512, 1, 512, 4608, nullptr);
+  if (has_tail) {
+    const float* real_cb = c->tail_b;
+    c->tail_b = zero;                       // bias-free pass: column i of Wfold = dec_nobias(tail_nobias(e_i))
+    for (int c0 = 0; c0 < KFOLD && !rc; c0 += CH) {
+      const size_t n = (size_t)CH * KFOLD;
+      hipLaunchKernelGGL(ita_impulse_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, imp, CH, KFOLD, c0);
+      if ((rc = launch_tail(c, imp, feat, 4608, CH, nullptr))) break;
+      rc = launch_gemm(feat, 4608, c->dec_w, 4608, nullptr, mt + (size_t)c0 * 512, 512, CH, 512, 4608, nullptr);
+    }
+    c->tail_b = real_cb;
+    if (!rc) {
+      // bias' = dec(tail(0)) with the real biases
+      HIPCHK(hipMemset(imp, 0, sizeof(float) * KFOLD));
+      if (!(rc = launch_tail(c, imp, feat, 4608, 1, nullptr)))
+        rc = launch_gemm(feat, 4608, c->dec_w, 4608, c->dec_b, imp, 512, 1, 512, 4608, nullptr);
+    }
+    if (!rc) {
+      HIPCHK(hipDeviceSynchronize());
+      HIPCHK(hipMemcpy(hb.data(), imp, 512 * sizeof(float), hipMemcpyDeviceToHost));
+    }
+  } else {
+    // Wfold^T[k][n] = dec_w[n][k]: transposed on the host (once, at load time); bias' = the decoder bias
+    const float *dw = hptr<float>(c, "dec.w"), *db = hptr<float>(c, "dec.b");
+    for (int n = 0; n < 512; ++n)
+      for (int k = 0; k < KFOLD; ++k) hmt[(size_t)k * 512 + n] = dw[(size_t)n * KFOLD + k];
+    HIPCHK(hipMemcpy(mt, hmt.data(), hmt.size() * sizeof(float), hipMemcpyHostToDevice));
+    memcpy(hb.data(), db, 512 * sizeof(float));
   }
   if (!rc) {
-    HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(hb.data(), imp, 512 * sizeof(float), hipMemcpyDeviceToHost));
     // one fold further: the decoder output feeds only LSTM layer 0, so
     //   G0^T[k][j] = sum_n Wfold^T[k][n] * W_ih0[j][n]        (wcat[0] holds W_ih0 in its first 517 columns)
     // computed with the exact f32 GEMM; the buffer that held the impulses is reused for the result
@@ -851,7 +865,9 @@ int ita_load_weights(ita_handle h, const void* blob, size_t nbytes) {
     }
   }
   h->loaded = true;
-  if (hdr.has_tail && hdr.E == 64 && h->tail_wT && h->dec_w && h->lw_hi[0]) {
+  h->kfold = 128 * hdr.E;
+  h->ldfold = h->kfold + 64;
+  if (((hdr.has_tail && hdr.E == 64 && h->tail_wT) || !hdr.has_tail) && h->dec_w && h->lw_hi[0]) {
     int rc2 = build_fold(h);
     if (rc2) { free_weights(h); return rc2; }
   }
@@ -1021,8 +1037,9 @@ static int forward_impl(ita_handle h, const void* image, int image_dtype, const 
   if ((!image && !x2_in) || !desvel || !quat || !h_in || !c_in || !vel || !h_out || !c_out)
     return fail(ITA_ERR_INVALID_ARG, "null pointer");
   if (image_dtype != ITA_IMAGE_F32 && image_dtype != ITA_IMAGE_U8) return fail(ITA_ERR_INVALID_ARG, "bad image dtype");
-  if (!h->hdr.has_tail || !h->dec_w || !h->wcat[0] || !h->fc_w)
-    return fail(ITA_ERR_BAD_BLOB, "blob holds no tail / decoder / LSTM parameters");
+  if (!h->dec_w || !h->wcat[0] || !h->fc_w || (h->hdr.has_tail && !h->tail_wT))
+    return fail(ITA_ERR_BAD_BLOB, "blob holds no decoder / LSTM (/ fusion tail) parameters");
+  if (h->hdr.has_tail && h->hdr.E != 64) return fail(ITA_ERR_UNSUPPORTED, "the fusion tail is built for E = 64 (ITAViTLSTM)");
   if ((rc = ensure_workspace(h, batch, (hipStream_t)stream))) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int B = batch;
@@ -1054,7 +1071,7 @@ static int forward_impl(ita_handle h, const void* image, int image_dtype, const 
     if (fast) {
       const size_t n = (size_t)B * 128 * h->hdr.E;
       hipLaunchKernelGGL(ita_split_planes_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, s, h->bufA, h->x2_hi,
-                         h->x2_lo, 128 * h->hdr.E, LDFOLD, B);
+                         h->x2_lo, 128 * h->hdr.E, h->ldfold, B);
       HIPCHK(hipGetLastError());
     }
     if (stage_h0) HIPCHK(hipMemcpyAsync(h->gates, h_in, sizeof(float) * (size_t)B * 128, hipMemcpyDeviceToDevice, s));
@@ -1077,8 +1094,8 @@ static int forward_impl(ita_handle h, const void* image, int image_dtype, const 
   if (taps && taps->x2) HIPCHK(hipMemcpyAsync(taps->x2, h->bufA, tokb, hipMemcpyDeviceToDevice, s));
   if (fast) {
     // folded tail+decoder: dec = x2 . Wfold^T + bias'   (x2 planes were written by the last FFN)
-    if ((rc = launch_gemm_split<128, 128, 2, 4>(h->x2_hi, h->x2_lo, LDFOLD, h->fold_hi, h->fold_lo, LDFOLD, h->part, B,
-                                                512, KFOLD, NSPLIT, s))) return rc;
+    if ((rc = launch_gemm_split<128, 128, 2, 4>(h->x2_hi, h->x2_lo, h->ldfold, h->fold_hi, h->fold_lo, h->ldfold, h->part, B,
+                                                512, h->kfold, NSPLIT, s))) return rc;
     MARK();
     MARK();
     _Float16* chi[3] = {nullptr, h->c1_hi, h->c2_hi};
@@ -1103,12 +1120,17 @@ static int forward_impl(ita_handle h, const void* image, int image_dtype, const 
     HIPCHK(hipGetLastError());
     MARK();
   } else {
-  if ((rc = launch_tail(h, h->bufA, h->feat, 4608, B, s))) return rc;
-    MARK();
-    if (taps && taps->feat)
-      HIPCHK(hipMemcpyAsync(taps->feat, h->feat, sizeof(float) * (size_t)B * 4608, hipMemcpyDeviceToDevice, s));
-    // decoder writes straight into the LSTM layer-0 concat buffer (columns 0..511)
-    if ((rc = launch_gemm(h->feat, 4608, h->dec_w, 4608, h->dec_b, h->cat0, K0P, B, 512, 4608, s))) return rc;
+    if (h->hdr.has_tail) {
+      if ((rc = launch_tail(h, h->bufA, h->feat, 4608, B, s))) return rc;
+      MARK();
+      if (taps && taps->feat)
+        HIPCHK(hipMemcpyAsync(taps->feat, h->feat, sizeof(float) * (size_t)B * 4608, hipMemcpyDeviceToDevice, s));
+      // decoder writes straight into the LSTM layer-0 concat buffer (columns 0..511)
+      if ((rc = launch_gemm(h->feat, 4608, h->dec_w, 4608, h->dec_b, h->cat0, K0P, B, 512, 4608, s))) return rc;
+    } else {   // no fusion tail: the decoder reads the flattened tokens, (B,128,E) as it stands in bufA
+      MARK();
+      if ((rc = launch_gemm(h->bufA, h->kfold, h->dec_w, h->kfold, h->dec_b, h->cat0, K0P, B, 512, h->kfold, s))) return rc;
+    }
     MARK();
     if (taps && taps->dec)
       HIPCHK(hipMemcpy2DAsync(taps->dec, 512 * sizeof(float), h->cat0, K0P * sizeof(float), 512 * sizeof(float), B,
@@ -1186,8 +1208,8 @@ static int front_impl(ita_handle h, const void* image, int image_dtype, int batc
   if ((rc = mark(1, true)) || (rc = mark(3, false))) return rc;
   if (encoder_done_event) HIPCHK(hipEventRecord((hipEvent_t)encoder_done_event, s));
   float* part = h->part + (size_t)buf * NSPLIT * h->cap * 512;
-  if ((rc = launch_gemm_split<128, 128, 2, 4>(h->x2_hi, h->x2_lo, LDFOLD, h->fold_hi, h->fold_lo, LDFOLD, part, batch, 512,
-                                              KFOLD, NSPLIT, s))) return rc;
+  if ((rc = launch_gemm_split<128, 128, 2, 4>(h->x2_hi, h->x2_lo, h->ldfold, h->fold_hi, h->fold_lo, h->ldfold, part, batch, 512,
+                                              h->kfold, NSPLIT, s))) return rc;
   if ((rc = mark(3, true))) return rc;
   if (ev && (h->prof_stage == 0 || h->prof_stage == 1 || h->prof_stage == 3)) ++h->prof_n;
   return ITA_OK;

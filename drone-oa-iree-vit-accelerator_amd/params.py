@@ -123,7 +123,7 @@ def blob_from_record(rec: dict, float_params: dict | None, E: int, num_layers: i
     has_tail = False
     if float_params is not None:
         t.update(float_tensors(float_params, num_layers))
-        has_tail = "dec.w" in t
+        has_tail = "tail.conv_w" in t     # without it the decoder reads the flattened tokens (models/ITA/QAT/model.py:80-81)
     return pack_blob(t, E=E, num_layers=num_layers, has_tail=has_tail)
 
 

@@ -23,10 +23,12 @@ def _uniform(rs, shape, bound):
 
 
 def float_params(seed: int, E: int = 64, P: int = 192, F: int = 256, num_layers: int = 1,
-                 gain_qk: float = 3.0) -> dict:
+                 gain_qk: float = 3.0, tail: bool = True) -> dict:
     """All float32 parameters of the float twin of the graph, PyTorch-default-like
     init bounds (U(-1/sqrt(fan_in), 1/sqrt(fan_in))), LayerNorm affine perturbed so it
-    is not the identity, q/k projections amplified so attention rows are peaky."""
+    is not the identity, q/k projections amplified so attention rows are peaky.
+    tail=False: the graph family without the fusion tail (models/ITA/QAT/model.py:22-87: the decoder reads the
+    flattened tokens, Linear(E * 128 -> 512)); the random stream of the tail=True form is untouched."""
     rs = np.random.RandomState(1000 + seed)
     p = {}
     p["tokenizer.conv.weight"] = _uniform(rs, (E, 1, 7, 7), 1 / 7.0)
@@ -49,10 +51,12 @@ def float_params(seed: int, E: int = 64, P: int = 192, F: int = 256, num_layers:
             p[nm + ".weight"] = (1.0 + 0.1 * rs.standard_normal(E)).astype(np.float32)
             p[nm + ".bias"] = (0.1 * rs.standard_normal(E)).astype(np.float32)
     cin = E // 4 + E
-    p["down_sample.weight"] = _uniform(rs, (9, cin, 3, 3), 1 / np.sqrt(cin * 9))
-    p["down_sample.bias"] = _uniform(rs, (9,), 1 / np.sqrt(cin * 9))
-    p["decoder.weight"] = _uniform(rs, (512, 4608), 1 / np.sqrt(4608))
-    p["decoder.bias"] = _uniform(rs, (512,), 1 / np.sqrt(4608))
+    if tail:
+        p["down_sample.weight"] = _uniform(rs, (9, cin, 3, 3), 1 / np.sqrt(cin * 9))
+        p["down_sample.bias"] = _uniform(rs, (9,), 1 / np.sqrt(cin * 9))
+    dec_in = 4608 if tail else E * 128
+    p["decoder.weight"] = _uniform(rs, (512, dec_in), 1 / np.sqrt(dec_in))
+    p["decoder.bias"] = _uniform(rs, (512,), 1 / np.sqrt(dec_in))
     k = 1 / np.sqrt(128)
     for l, fi in enumerate((517, 128, 128)):
         p[f"lstm.weight_ih_l{l}"] = _uniform(rs, (512, fi), k)

@@ -18,6 +18,7 @@
  *
  * Reference lines followed (all under /root/reference):
  *   refine_inputs / forward ........ models/ITA_single_layer_upsample_shuffle/QAT/model.py:22-31,93-132
+ *   forward without the fusion tail  models/ITA/QAT/model.py:62-87 (2 layers, E = 128, decoder on the flattened tokens)
  *   OverlapPatchMerging ............ models/ITA/QAT/layers.py:25-45
  *   ITASelfAttention_QAT ........... models/ITA/QAT/layers.py:77-127
  *   ITAFeedForward_QAT ............. models/ITA/QAT/layers.py:47-75
@@ -435,7 +436,9 @@ int ita_oracle_forward(const void* blob, size_t nbytes, const void* image, int i
   const ita_blob_header* hd = (const ita_blob_header*)blob;
   if (nbytes < sizeof(*hd) || memcmp(hd->magic, ITA_BLOB_MAGIC, 8) != 0) return -1;
   const int E = hd->E, S = hd->S, P = hd->P, F = hd->F, L = hd->num_layers;
-  if (S != 128 || hd->H != 1 || !hd->has_tail) return -2;
+  if (S != 128 || hd->H != 1) return -2;
+  if (!GET("dec.w") || !GET("lstm.w_ih0") || !GET("fc.w")) return -2;   /* a blocks-only blob has no whole graph */
+  const int has_tail = hd->has_tail;   /* 0: models/ITA/QAT/model.py:80-81 -- the decoder reads the flattened tokens */
   const size_t tokn = (size_t)B * S * E;
   float* img = (float*)malloc(sizeof(float) * (size_t)B * IMG_H * IMG_W);
   if (image_is_u8) ita_oracle_u8_to_f32((const uint8_t*)image, (size_t)B * IMG_H * IMG_W, img);
@@ -465,9 +468,13 @@ int ita_oracle_forward(const void* blob, size_t nbytes, const void* image, int i
 #undef N_
   }
   if (t_x2) memcpy(t_x2, x, sizeof(float) * tokn);
-  ita_oracle_tail(x, B, E, (const float*)GET("tail.conv_w"), (const float*)GET("tail.conv_b"), feat, 0);
-  if (t_feat) memcpy(t_feat, feat, sizeof(float) * (size_t)B * 4608);
-  ita_oracle_linear_f32(feat, B, 4608, 512, (const float*)GET("dec.w"), (const float*)GET("dec.b"), dec);
+  if (has_tail) {
+    ita_oracle_tail(x, B, E, (const float*)GET("tail.conv_w"), (const float*)GET("tail.conv_b"), feat, 0);
+    if (t_feat) memcpy(t_feat, feat, sizeof(float) * (size_t)B * 4608);
+    ita_oracle_linear_f32(feat, B, 4608, 512, (const float*)GET("dec.w"), (const float*)GET("dec.b"), dec);
+  } else {   /* x.flatten(1): token-major, channel fastest -- the (B,128,E) layout as it stands */
+    ita_oracle_linear_f32(x, B, S * E, 512, (const float*)GET("dec.w"), (const float*)GET("dec.b"), dec);
+  }
   if (t_dec) memcpy(t_dec, dec, sizeof(float) * (size_t)B * 512);
   for (int b = 0; b < B; ++b) {
     memcpy(cat + (size_t)b * 517, dec + (size_t)b * 512, sizeof(float) * 512);

@@ -455,3 +455,46 @@ def test_tail_from_reference_x2_within_1e4(torch_cuda, oracle, path):
             np.testing.assert_allclose(vel.cpu().numpy(), ovel, atol=2e-5, rtol=0)
             np.testing.assert_allclose(h.cpu().numpy(), oh, atol=2e-5, rtol=0)
     eng.close()
+
+
+FIX_2L = golden_files("vit2l_*.npz")
+
+
+@pytest.mark.parametrize("mode", [1, 0], ids=["tail_f16x3", "tail_exact_f32"])
+@pytest.mark.parametrize("path", FIX_2L, ids=_ids(FIX_2L))
+def test_two_layer_e128_no_tail_graph(torch_cuda, oracle, path, mode):
+    """The second graph family end to end (models/ITA/QAT/model.py:22-87; the only graph whose attention marker
+    ITA_spec.mlir:69-85 matches): E = 128, two encoder layers, decoder on the flattened tokens.  Tokenizer launch,
+    per layer the stream attention kernel (+ LayerNorm1) and the FFN block kernel (+ LayerNorm2), folded GEMM with
+    K = 16384, LSTM head.  Everything up to x2 equals the oracle; the head within 2e-5 (mode 1) / equal (mode 0); and
+    the reference's own fixture within the end-to-end int8 bound."""
+    torch = torch_cuda
+    d = params.load_fixture(path)
+    fp = synth.float_params(int(d["meta.seed"]), E=128, num_layers=2, tail=False)
+    blob = params.blob_from_record(d, fp, E=128, num_layers=2)
+    eng = host.Engine(blob, device=0)
+    eng.set_tail_mode(mode)
+    cu = lambda a: torch.from_numpy(a).cuda()
+    vel, (h, c), tp = eng.forward(cu(d["in0.img_u8"]), cu(d["in0.desvel"]), cu(d["in0.quat"]), taps=True)
+    ovel, oh, oc, otp = oracle.forward(blob, d["in0.img_u8"], d["in0.desvel"], d["in0.quat"], taps=True)
+    for k in ("tokens", "x1", "x2"):
+        np.testing.assert_array_equal(tp[k].cpu().numpy(), otp[k], err_msg=k)
+    if mode == 0:
+        np.testing.assert_array_equal(tp["dec"].cpu().numpy(), otp["dec"])
+        np.testing.assert_array_equal(vel.cpu().numpy(), ovel)
+        np.testing.assert_array_equal(h.cpu().numpy(), oh)
+        np.testing.assert_array_equal(c.cpu().numpy(), oc)
+    else:
+        for got, want in ((vel, ovel), (h, oh), (c, oc)):
+            np.testing.assert_allclose(got.cpu().numpy(), want, atol=2e-5, rtol=0)
+    for got, key in ((vel, "s0.vel"), (h, "s0.h"), (c, "s0.c")):
+        np.testing.assert_allclose(got.cpu().numpy(), d[key], atol=5e-4, rtol=0, err_msg=key)
+    # second time step with carried state, and a batch beyond one frame per workgroup
+    vel1, _ = eng.forward(cu(d["in1.img_u8"]), cu(d["in1.desvel"]), cu(d["in1.quat"]), (cu(d["s0.h"]), cu(d["s0.c"])))
+    np.testing.assert_allclose(vel1.cpu().numpy(), d["s1.vel"], atol=5e-4, rtol=0)
+    fr = synth.frames(88, 260)
+    v, _ = eng.forward(cu(fr["img_u8"]), cu(fr["desvel"]), cu(fr["quat"]))
+    sel = [0, 255, 256, 259]
+    ov, _, _ = oracle.forward(blob, fr["img_u8"][sel], fr["desvel"][sel], fr["quat"][sel])
+    np.testing.assert_allclose(v.cpu().numpy()[sel], ov, atol=2e-5 if mode == 1 else 0, rtol=0)
+    eng.close()

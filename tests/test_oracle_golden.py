@@ -189,3 +189,38 @@ def test_full_forward_two_steps(oracle, path):
     img_f = d["in0.img_u8"].astype(np.float32) / np.float32(255.0)
     vel0f, _, _ = oracle.forward(blob, img_f, d["in0.desvel"], d["in0.quat"])
     np.testing.assert_array_equal(vel0f, vel0)
+
+
+FIX_2L = golden_files("vit2l_*.npz")
+
+
+@pytest.mark.parametrize("path", FIX_2L, ids=_ids(FIX_2L))
+def test_two_layer_no_tail_graph(oracle, path):
+    """The second graph family (models/ITA/QAT/model.py:22-87): E = 128, two encoder layers, no fusion tail -- the
+    decoder reads the flattened tokens.  Fixture = the reference's own module run through its QAT flow
+    (tools/gen_golden.py: gen_vit2l).  Same bounds as the ITAViTLSTM fixtures: float stages 2e-5, end to end 5e-4
+    (an int8 code can flip behind a float LayerNorm), isolated flips only."""
+    d = params.load_fixture(path)
+    fp = synth.float_params(int(d["meta.seed"]), E=128, num_layers=2, tail=False)
+    assert synth.digest(fp) == str(d["meta.params_sha256"])
+    blob = params.blob_from_record(d, fp, E=128, num_layers=2)
+    assert np.frombuffer(blob[8 + 4 * 7:8 + 4 * 8], np.int32)[0] == 0           # has_tail = 0
+    # layer 0 block by block from the reference's own block inputs: bit-exact int8 codes
+    t0 = params.attention_tensors(d, "attn0.", 0)
+    t0.update(params.ffn_tensors(d, "ffn0.", 0))
+    _, tp = oracle.mha(d["s0.tok.out"], t0, taps=True)
+    np.testing.assert_array_equal(tp["x_q"], d["s0.attn0.x_q"])
+    assert (tp["out_q"] != d["s0.attn0.out_q"]).mean() < 2e-3                    # near-tie logits only (see test_mha)
+    vel0, h0, c0, tpf = oracle.forward(blob, d["in0.img_u8"], d["in0.desvel"], d["in0.quat"], taps=True)
+    np.testing.assert_allclose(tpf["tokens"], d["s0.tok.out"], atol=2e-5, rtol=0)
+    assert np.mean(np.abs(tpf["x2"] - d["s0.x2_1"]) > 1e-4) < 5e-3
+    np.testing.assert_allclose(tpf["dec"], d["s0.dec"], atol=5e-3, rtol=0)
+    for got, key in ((vel0, "s0.vel"), (h0, "s0.h"), (c0, "s0.c")):
+        np.testing.assert_allclose(got, d[key], atol=5e-4, rtol=0, err_msg=key)
+    vel1, h1, c1 = oracle.forward(blob, d["in1.img_u8"], d["in1.desvel"], d["in1.quat"], d["s0.h"], d["s0.c"])
+    for got, key in ((vel1, "s1.vel"), (h1, "s1.h"), (c1, "s1.c")):
+        np.testing.assert_allclose(got, d[key], atol=5e-4, rtol=0, err_msg=key)
+    # the float head from the reference's decoder output: 1e-6
+    fpr = dict(fp)
+    vel, h, c = oracle.head_from_dec(d["s0.dec"], d["in0.desvel"], d["in0.quat"], fpr)
+    np.testing.assert_allclose(vel, d["s0.vel"], atol=1e-6, rtol=0)

@@ -200,6 +200,63 @@ def gen_vitlstm(seed, B, out_dir):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def gen_vit2l(seed, B, out_dir):
+    """The graph family WITHOUT the fusion tail: models/ITA/QAT/model.py:22-87 -- E = 128, two encoder layers, decoder
+    Linear(E*S -> 512) on the flattened tokens, then the same LSTM head.  Same QAT flow as gen_vitlstm (qconfig on the
+    attention / FFN blocks only, calibration, convert, the validation harness's matmul2).  This repo's synthetic
+    parameters use the names norms1.i / norms2.i; the reference module calls them norm1_layers.i / norm2_layers.i."""
+    from models.ITA.QAT.model import ITALSTMNetVIT_QAT as ITAViT2L
+    fp = synth.float_params(seed, E=128, num_layers=2, tail=False)
+    model = ITAViT2L()
+    ren = lambda k: k.replace("norms1.", "norm1_layers.").replace("norms2.", "norm2_layers.")
+    sd = model.state_dict()
+    for k, v in fp.items():
+        assert ren(k) in sd and tuple(sd[ren(k)].shape) == v.shape, k
+    model.load_state_dict({ren(k): torch.from_numpy(v) for k, v in fp.items()}, strict=True)
+    model.attention_blocks.qconfig = ita_symmetric_qconfig     # training/qa_train.py:67-68
+    model.ffn_blocks.qconfig = ita_symmetric_qconfig
+    prepared = torch.ao.quantization.prepare_qat(model.train())
+    prepared.lstm.dropout = 0.0
+    with torch.no_grad():
+        for it in range(4):
+            prepared(to_X(synth.frames(100 * seed + 70 + it, 8, gain=0.8)))
+    conv = torch.ao.quantization.convert(prepared.eval())
+    for blk in conv.attention_blocks:
+        blk.matmul2.matmul = patched_matmul2(blk.matmul2.scale, blk.matmul2.zero_point)
+    tap = Tap()
+    tap.add(conv.tokenizer, "tok.out")
+    for i in range(2):
+        tap_attention(tap, conv.attention_blocks[i], f"attn{i}.")
+        tap_ffn(tap, conv.ffn_blocks[i], f"ffn{i}.")
+        tap.add(conv.norm1_layers[i], f"x1_{i}")
+        tap.add(conv.norm2_layers[i], f"x2_{i}")
+    tap.add(conv.decoder, "dec")
+    fr0, fr1 = synth.frames(10 * seed + 5, B), synth.frames(10 * seed + 6, B)
+    with torch.no_grad():
+        vel0, (h0, c0) = conv(to_X(fr0, None))
+        stage = dict(tap.t)
+        vel1, (h1, c1) = conv(to_X(fr1, (h0, c0)))
+    rec = {"meta.seed": np.int64(seed), "meta.B": np.int64(B), "meta.E": np.int64(128), "meta.num_layers": np.int64(2),
+           "meta.params_sha256": np.array(synth.digest(fp)), "meta.torch": np.array(torch.__version__),
+           "meta.engine": np.array("qnnpack")}
+    for i in range(2):
+        rec.update(block_quant_record(f"attn{i}.", attn=conv.attention_blocks[i]))
+        rec.update(block_quant_record(f"ffn{i}.", ffn=conv.ffn_blocks[i]))
+    for k, v in fr0.items():
+        rec["in0." + k] = v
+    for k, v in fr1.items():
+        rec["in1." + k] = v
+    keep = ("tok.out", "x1_0", "x2_0", "x1_1", "x2_1", "dec", "attn0.x_q", "attn0.out_q", "ffn0.out_q", "attn1.x_q", "attn1.probs",
+            "attn1.out_q", "ffn1.h1_relu", "ffn1.out_q")
+    for k in keep:      # a selection: the per-stage int8 tensors of an E = 128 block are pinned by blocks_E128_*.npz already
+        rec["s0." + k] = stage[k]
+    rec["s0.vel"] = vel0.numpy(); rec["s0.h"] = h0.numpy(); rec["s0.c"] = c0.numpy()
+    rec["s1.vel"] = vel1.numpy(); rec["s1.h"] = h1.numpy(); rec["s1.c"] = c1.numpy()
+    path = os.path.join(out_dir, f"vit2l_E128_s{seed}_B{B}.npz")
+    np.savez_compressed(path, **rec)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 class _Blocks(torch.nn.Module):
     """container so that prepare_qat/convert see the reference blocks as children"""
 
@@ -354,7 +411,7 @@ def gen_float_twin(seed, B, out_dir):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
-    ap.add_argument("--only", default="", help="comma list of: softmax, vitlstm, blocks, tail_large, float_twin (default: all)")
+    ap.add_argument("--only", default="", help="comma list of: softmax, vitlstm, blocks, tail_large, float_twin, vit2l (default: all)")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     only = set(filter(None, a.only.split(",")))
@@ -367,8 +424,10 @@ def main():
             gen_blocks(2, 64, 1, a.out, gain_qk=6.0)
         if "tail_large" in only: gen_tail_large(a.out)
         if "float_twin" in only: gen_float_twin(0, 2, a.out)
+        if "vit2l" in only: gen_vit2l(0, 2, a.out)
         return
     gen_float_twin(0, 2, a.out)
+    gen_vit2l(0, 2, a.out)
     gen_softmax(a.out)
     for seed in (0, 1, 2):
         gen_vitlstm(seed, 2, a.out)
