@@ -184,10 +184,29 @@ def bench_c2(frames=1024, iters=50):
             eng.mha(x1)
             torch.cuda.synchronize()
             lat.append(time.perf_counter() - t1)
-        tops = mop * frames / ms / 1e9
-        out[f"E{E}"] = {"kernel": f"ita_stream_kernel<{E}, false, 0, false>", "frames": frames, "ms_per_launch": round(ms, 5),
-                        "frames_per_s": round(frames / ms * 1e3, 1), "ops_per_launch": mop * frames,
-                        "achieved_TOPs": round(tops, 1), "peak_TOPs": 5000.0, "frac": round(tops / 5000.0, 4),
+        # the same block at the accelerator's own boundary: int8 codes in, int8 codes out (ita_mha_q8) -- the form
+        # SURVEY.md section 8(d) prices config 2 on (32 KiB of HBM traffic per E = 128 frame instead of 128 KiB)
+        xq = torch.randint(-128, 128, (frames, 128, E), device="cuda", dtype=torch.int8)
+        for _ in range(5):
+            eng.mha_q8(xq)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            eng.mha_q8(xq)
+        e1.record()
+        torch.cuda.synchronize()
+        ms8 = e0.elapsed_time(e1) / iters
+        tops, tops8 = mop * frames / ms / 1e9, mop * frames / ms8 / 1e9
+        out[f"E{E}"] = {"frames": frames, "ops_per_launch": mop * frames, "peak_TOPs": 5000.0,
+                        "int8_io": {"kernel": f"ita_stream_kernel<{E}, false, 0, false, true>", "entry": "ita_mha_q8",
+                                    "ms_per_launch": round(ms8, 5), "frames_per_s": round(frames / ms8 * 1e3, 1),
+                                    "achieved_TOPs": round(tops8, 1), "frac": round(tops8 / 5000.0, 4),
+                                    "hbm_bytes_per_launch": 2 * 128 * E * frames},
+                        "f32_io": {"kernel": f"ita_stream_kernel<{E}, false, 0, false, false>", "entry": "ita_mha_int8",
+                                   "ms_per_launch": round(ms, 5), "frames_per_s": round(frames / ms * 1e3, 1),
+                                   "achieved_TOPs": round(tops, 1), "frac": round(tops / 5000.0, 4),
+                                   "hbm_bytes_per_launch": 2 * 128 * E * 4 * frames},
+                        "frac": round(tops8 / 5000.0, 4),
                         "p50_latency_ms_b1": round(float(np.median(lat[50:])) * 1e3, 4)}
         eng.close()
     return {"workload": "int8 MHA block alone (ita_mha_int8): quantise, Q/K/V, QK^T, integer softmax, A.V, out_proj, "

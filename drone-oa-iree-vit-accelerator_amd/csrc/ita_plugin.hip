@@ -371,6 +371,8 @@ bool stream_range_ok(const StreamHostParams& p, int E, bool ffn) {
 }
 
 struct StreamIo {
+  const int8_t* xq = nullptr;   // int8 in / int8 out attention block (mode 2)
+  int8_t* yq = nullptr;
   const float* x = nullptr;
   float* y = nullptr;
   _Float16 *y_hi = nullptr, *y_lo = nullptr;
@@ -393,9 +395,14 @@ int launch_stream(ita_context* c, int layer, int mode, bool fuse_ln, const Strea
   a.f_inv_sx = L.fscal[ITA_F_INV_SX]; a.m1 = L.fscal[ITA_F_M1]; a.m2 = L.fscal[ITA_F_M2]; a.s2 = L.fscal[ITA_F_S2];
   a.B = B; a.fuse_ln = fuse_ln ? 1 : 0;
   a.stamps = io.stamps; a.h0_src = io.h0_src; a.h0_dst = io.h0_dst; a.slots = io.slots;
-  a.img = io.img; a.tok_tap = io.tok_tap;
+  a.img = io.img; a.tok_tap = io.tok_tap; a.xq = io.xq; a.yq = io.yq;
   const int grid = B < c->num_cus ? B : c->num_cus;
-  if (mode == 1) {
+  if (mode == 2) {
+    if (!L.simg_mha) return fail(ITA_ERR_UNSUPPORTED, "this layer has no attention image (accumulator range)");
+    a.image = L.simg_mha;
+    if (c->hdr.E == 64) hipLaunchKernelGGL((ita_stream_kernel<64, false, 0, false, true>), dim3(grid), dim3(512), (ItaStreamLds<64, false, false>::TOTAL), s, a);
+    else hipLaunchKernelGGL((ita_stream_kernel<128, false, 0, false, true>), dim3(grid), dim3(512), (ItaStreamLds<128, false, false>::TOTAL), s, a);
+  } else if (mode == 1) {
     if (!L.simg_mha) return fail(ITA_ERR_BAD_BLOB, "attention image missing");
     if (fuse_ln && !L.n1w) return fail(ITA_ERR_BAD_BLOB, "norm1 parameters missing from the blob");
     a.image = L.simg_mha;
@@ -691,6 +698,8 @@ int ita_create(ita_handle* out, int device_ordinal) {
   if ((rc = set_lds(ita_stream_kernel<64, true, 0, true>, ItaStreamLds<64, true, false>::TOTAL))) { delete c; return rc; }
   if ((rc = set_lds(ita_stream_kernel<64, false, 0>, ItaStreamLds<64, false, false>::TOTAL))) { delete c; return rc; }
   if ((rc = set_lds(ita_stream_kernel<128, false, 0>, ItaStreamLds<128, false, false>::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_stream_kernel<64, false, 0, false, true>, ItaStreamLds<64, false, false>::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_stream_kernel<128, false, 0, false, true>, ItaStreamLds<128, false, false>::TOTAL))) { delete c; return rc; }
   {
     auto k1 = ita_gemm_f16x3_kernel<128, 128, 2, 4>;
     constexpr int b1 = ItaGemmSplitLds<128, 128>::TOTAL;
@@ -910,6 +919,15 @@ int ita_mha_int8_taps(ita_handle h, int layer, const float* x, float* y, int bat
 }
 int ita_mha_int8(ita_handle h, int layer, const float* x, float* y, int batch, void* stream) {
   return ita_mha_int8_taps(h, layer, x, y, batch, nullptr, stream);
+}
+
+int ita_mha_q8(ita_handle h, int layer, const int8_t* x_q, int8_t* out_q, int batch, void* stream) {
+  int rc = check(h, batch);
+  if (rc) return rc;
+  if (!x_q || !out_q || layer < 0 || layer >= h->hdr.num_layers) return fail(ITA_ERR_INVALID_ARG, "bad pointer or layer");
+  StreamIo io;
+  io.xq = x_q; io.yq = out_q;
+  return launch_stream(h, layer, 2, false, io, batch, (hipStream_t)stream);
 }
 
 int ita_ffn_int8_taps(ita_handle h, int layer, const float* x, float* y, int batch, const ita_ffn_taps* taps,

@@ -49,6 +49,9 @@ struct ItaStreamArgs {
   const float* h0_src;
   float* h0_dst;
   const int* slots;
+  // int8 in / int8 out form of the attention block (IO8: the accelerator-native boundary):
+  const int8_t* xq;       // (B,128,E) quantised block input
+  int8_t* yq;             // (B,128,E) out_proj codes (no dequantisation, no residual)
   const void* img;        // (B,60,90) u8 wire frames (TOK == 1)
   float* tok_tap;         // optional (B,128,E): the tokens
 };
@@ -300,8 +303,9 @@ __device__ __forceinline__ void dq_group(const i32x4 (&acc)[4], float mult, floa
 
 // (amdgpu_waves_per_eu(2, 2): the workgroup owns the CU's LDS, so two waves per SIMD is all there will ever be -- without
 // it the scheduler trades instruction-level parallelism for registers it has no use for: the LDS size is dynamic)
-template <int E, bool FFN, int TOK, bool STAMP = false>
+template <int E, bool FFN, int TOK, bool STAMP = false, bool IO8 = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void ita_stream_kernel(const ItaStreamArgs a) {
+  static_assert(!IO8 || (!FFN && TOK == 0), "int8 I/O is the attention block's form");
   using L = ItaStreamLds<E, FFN, TOK != 0>;
   constexpr int S = 128, P = 192, F = 256, EC = E / 4, NK = E / 64, NTE = E / 16;
   static_assert(!TOK || (E == 64 && FFN), "the fused tokenizer is built for the ITAViTLSTM shape");
@@ -429,6 +433,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // first, then the tokenizer's tables (the tail of the image), then the 84 KB of weights -- which stay in flight, in
   // registers, while the first frame is tokenized, and only then go to LDS.
   float xr[EC];
+  i32x4 xq_cur[NK];       // IO8: this lane's k-slots of the block input, as they stand in memory
   f32x4 h0_cur = {0.0f, 0.0f, 0.0f, 0.0f};
   int h0_row_next = 0;
   {
@@ -436,6 +441,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("" : "+v"(ol));
     if constexpr (TOK != 0) {
       tok_fetch(blockIdx.x, ol);
+    } else if constexpr (IO8) {
+      const int8_t* xrow = a.xq + ((size_t)blockIdx.x * S + wave * 16 + (ol & 15)) * E + EC * (ol >> 4);
+#pragma unroll
+      for (int c = 0; c < NK; ++c) xq_cur[c] = *(const i32x4*)(xrow + 16 * c);
     } else {
       const float* xrow = a.x + ((size_t)blockIdx.x * S + wave * 16 + (ol & 15)) * E + EC * (ol >> 4);
 #pragma unroll
@@ -504,9 +513,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     i32x4 xf[NK];
 #pragma unroll
     for (int c = 0; c < NK; ++c) {
-      unsigned p4[4];
-      q_pack16(&xr[16 * c], a.inv_sx, p4);
-      xf[c] = (i32x4){(int)p4[0], (int)p4[1], (int)p4[2], (int)p4[3]};
+      if constexpr (IO8) {
+        xf[c] = xq_cur[c];
+      } else {
+        unsigned p4[4];
+        q_pack16(&xr[16 * c], a.inv_sx, p4);
+        xf[c] = (i32x4){(int)p4[0], (int)p4[1], (int)p4[2], (int)p4[3]};
+      }
     }
     // side copy of the LSTM layer-0 state row (see ItaStreamArgs): the row was requested a phase ago -- a load waited
     // for here would hold wave 0, and with it the whole workgroup's next barrier, for a full memory latency
@@ -566,8 +579,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (!(ITA_ABLATE & 128) && a.h0_dst && tid < 32 && nb < a.B)
       h0_cur = *(const f32x4*)(a.h0_src + (size_t)h0_row_next * 128 + 4 * tid);
     float xn[EC];
+    i32x4 xq_nxt[NK];
     if constexpr (TOK != 0) {
       if (nb < a.B) tok_fetch(nb, ol);
+    } else if constexpr (IO8) {
+      const int8_t* xnrow = a.xq + ((size_t)min(nb, a.B - 1) * S + token) * E + EC * kq;
+#pragma unroll
+      for (int c = 0; c < NK; ++c) xq_nxt[c] = *(const i32x4*)(xnrow + 16 * c);
     } else {
       const float* xnrow = a.x + ((size_t)min(nb, a.B - 1) * S + token) * E + EC * kq;
 #pragma unroll
@@ -690,11 +708,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         ITA_SCHED_BARRIER();   // keep the step's loads ahead of the next step's MFMAs
       }
       if constexpr (TOK != 0 && ITA_TOK_MID && !(ITA_ABLATE & 4)) { if (more) { tok_step(0, ol); tok_step(1, ol); } }
+      if constexpr (IO8) {   // the int8 codes themselves: 16 channels of this lane's token, one 16-byte store
+        *(i32x4*)(a.yq + ((size_t)b * S + token) * E + EC * kq + 16 * eg) = rq_group(oa, a.mo, -128.0f);
+        if (eg + 1 < EG) ld_obias<E>(oa, l_bo, 4 * (eg + 1), kq);
+        continue;
+      }
       float d[16];
       dq_group(oa, a.mo, a.so, d);
       if (eg + 1 < EG) ld_obias<E>(oa, l_bo, 4 * (eg + 1), kq);
 #pragma unroll
       for (int j = 0; j < 16; ++j) x1[16 * eg + j] = (FFN || a.fuse_ln) ? xr[16 * eg + j] + d[j] : d[j];
+    }
+    if constexpr (IO8) {
+#pragma unroll
+      for (int c = 0; c < NK; ++c) xq_cur[c] = xq_nxt[c];
+      continue;
     }
     if constexpr (TOK != 0 && ITA_TOK_MID && !(ITA_ABLATE & 4)) { if (more) { tok_step(2, ol); tok_step(3, ol); } }
     if (FFN || a.fuse_ln) layernorm_q16<E>(x1, lnp, lnp + E, EC * kq);

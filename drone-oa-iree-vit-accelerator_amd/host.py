@@ -29,7 +29,7 @@ DISPATCH_F16, DISPATCH_F32 = 0, 1
 
 EXPORTED_SYMBOLS = (
     "ita_abi_version", "ita_create", "ita_destroy", "ita_load_weights", "ita_validate_blob", "ita_reserve", "ita_get_dims",
-    "ita_last_error", "ita_error_string", "ita_mha_int8", "ita_mha_int8_taps", "ita_ffn_int8", "ita_ffn_int8_taps",
+    "ita_last_error", "ita_error_string", "ita_mha_int8", "ita_mha_int8_taps", "ita_mha_q8", "ita_ffn_int8", "ita_ffn_int8_taps",
     "ita_encoder_layer", "ita_tokenizer", "ita_fusion_tail", "ita_vitlstm_forward", "ita_bind_dispatch",
     "ita_profile_begin", "ita_profile_begin_sampled", "ita_profile_end", "ita_set_tail_mode", "ita_debug_encoder_stamps",
     "ita_fusion_tail_load", "ita_fusion_tail_large",
@@ -116,6 +116,7 @@ def lib():
         L.ita_vitlstm_front.argtypes = [vp, vp, i, i, i, vp]
         L.ita_vitlstm_front_ev.argtypes = [vp, vp, i, i, i, vp, vp]
         L.ita_vitlstm_back.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp]
+        L.ita_mha_q8.argtypes = [vp, i, vp, vp, i, vp]
         L.ita_vitlstm_tail.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, vp]
         L.ita_debug_softmax_rows.argtypes = [vp, vp, vp, i, vp]
         L.ita_validate_blob.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
@@ -302,6 +303,15 @@ class Engine:
         if taps:
             return vel, (h_out, c_out), tp
         return vel, (h_out, c_out)
+
+    def mha_q8(self, x_q, layer: int = 0):
+        """attention block on int8 codes: x_q (B,128,E) int8 -> out_q (B,128,E) int8 (ita_mha_q8)"""
+        torch = _torch()
+        assert x_q.dtype == torch.int8 and x_q.is_cuda and tuple(x_q.shape[1:]) == (128, self.E)
+        x_q = x_q.contiguous()
+        out = torch.empty_like(x_q)
+        _chk(lib().ita_mha_q8(self._h, layer, x_q.data_ptr(), out.data_ptr(), x_q.shape[0], _stream_ptr(self.device)))
+        return out
 
     def softmax_rows(self, logits):
         """IntegerApproximatedSoftmax through the encoder kernel's own device function: int8 (R,128) -> uint8 (R,128)"""

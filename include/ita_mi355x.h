@@ -89,6 +89,12 @@ typedef struct ita_mha_taps {
 int ita_mha_int8_taps(ita_handle h, int layer, const float* x_dev, float* y_dev, int batch,
                       const ita_mha_taps* taps, void* stream);
 
+/* The same block at the accelerator's own boundary: int8 codes in (what `quant` produces, layers.py:103), int8 out_proj
+ * codes out (what `dequant` consumes, layers.py:125) -- x_q, out_q (B,128,E) s8 device pointers.  This is the form
+ * SURVEY.md section 8(d) prices BASELINE config 2 on (32 KiB of HBM traffic per E = 128 frame instead of 128 KiB).
+ * Equal, byte for byte, to the x_q -> out_q taps of ita_mha_int8_taps. */
+int ita_mha_q8(ita_handle h, int layer, const int8_t* x_q_dev, int8_t* out_q_dev, int batch, void* stream);
+
 /* ITAFeedForward_QAT.forward (models/ITA/QAT/layers.py:61-75). */
 int ita_ffn_int8(ita_handle h, int layer, const float* x_dev, float* y_dev, int batch, void* stream);
 typedef struct ita_ffn_taps { int8_t *x_q, *h, *out_q; } ita_ffn_taps;

@@ -69,6 +69,19 @@ def test_mha_block_bit_exact(torch_cuda, oracle, path):
     np.testing.assert_array_equal(taps["probs"].cpu().numpy()[rows_ok], d["s0.attn0.probs"][:, 0][rows_ok])
     np.testing.assert_array_equal(taps["out_q"].cpu().numpy()[rows_ok], d["s0.attn0.out_q"][rows_ok])
     np.testing.assert_array_equal(y.cpu().numpy()[rows_ok], d["s0.attn0.out_f"][rows_ok])
+    # the tap-less entry runs a different kernel (ita_stream_kernel: weights resident in LDS, activations chained
+    # through registers): same bits; and the int8-in / int8-out form of it (ita_mha_q8) maps x_q to out_q
+    np.testing.assert_array_equal(eng.mha(torch.from_numpy(x).cuda()).cpu().numpy(), oy)
+    np.testing.assert_array_equal(eng.mha_q8(taps["x_q"]).cpu().numpy(), otaps["out_q"])
+    rs = np.random.RandomState(3)
+    xq = rs.randint(-128, 128, size=(259, 128, E)).astype(np.int8)                 # beyond one frame per workgroup
+    got = eng.mha_q8(torch.from_numpy(xq).cuda()).cpu().numpy()
+    t = _block_tensors(d)
+    inv = float(t["attn0.scal"][0])
+    sel = [0, 1, 255, 256, 258]
+    _, ot = oracle.mha(xq[sel].astype(np.float32) / np.float32(inv), t, taps=True)   # codes / inv_sx quantise back to the codes
+    if np.array_equal(ot["x_q"], xq[sel]):
+        np.testing.assert_array_equal(got[sel], ot["out_q"])
     eng.close()
 
 
