@@ -8,7 +8,9 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-latency $*"
+# (no --no-configs: the same command also runs BASELINE config 2 and 5, so ita_stream_kernel<128, false, ...> and
+#  ita_tail_big_kernel get their kernel stats and counters from this run too)
+ARGS="--steps 24 --warmup 8 --no-cpu-baseline --no-latency $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py $ARGS > $OUT/stats.log 2>&1
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
