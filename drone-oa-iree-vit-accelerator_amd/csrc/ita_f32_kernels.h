@@ -43,8 +43,7 @@ struct ItaTokLds {
   static constexpr int WT = IMG + PH * PW * 4;
   static constexpr int WAVE0 = WT + 50 * E * 4;
   static constexpr int WAVE_BYTES = 32 * E * 4 > 32 * PBS * 4 ? 32 * E * 4 : 32 * PBS * 4;
-  static constexpr int LUT = WAVE0 + 4 * WAVE_BYTES;      // f32[256]: k / 255.0f (u8 wire frames)
-  static constexpr int TOTAL = LUT + 256 * 4;
+  static constexpr int TOTAL = WAVE0 + 4 * WAVE_BYTES;
 };
 
 template <int E, bool U8>
@@ -77,7 +76,10 @@ __global__ __launch_bounds__(256) void ita_tokenizer_kernel(const ItaTokArgs a) 
   float ly, lx;
   bilinear_src_dev(tg >> 4, 30.0f / 8.0f, 30, y0, yp, ly);
   bilinear_src_dev(tg & 15, 45.0f / 16.0f, 45, x0, xp, lx);
-  const float h1 = ly, h0 = 1.0f - ly, w1 = lx, w0 = 1.0f - lx;
+  // u8 wire frames: the pixel CODES are blended with the integer weights H = 8h, W = 32w (the weights of this fixed
+  // resize are dyadic), every product and sum an exact integer <= 255 * 256 in f32, and 1 / 65280 is in the conv
+  // weights (a.cw points at the scaled copy) -- oracle/ita_oracle.c ita_oracle_tokenizer_u8
+  const float h1 = U8 ? 8.0f * ly : ly, h0 = (U8 ? 8.0f : 1.0f) - h1, w1 = U8 ? 32.0f * lx : lx, w0 = (U8 ? 32.0f : 1.0f) - w1;
   const int r = lane & 31, kk = lane >> 5;
   // per-thread constants kept in registers for the whole launch: this thread's LayerNorm affine
   // parameters (loading them per frame exposed one L2 latency per frame) ...
@@ -90,10 +92,6 @@ __global__ __launch_bounds__(256) void ita_tokenizer_kernel(const ItaTokArgs a) 
   }
 
   for (int i = tid; i < L::PH * PW; i += 256) img[i] = 0.0f;   // the zero border is written once
-  // u8 -> f32 exactly as the reference host does it, float(pixel) / 255.0f (main.cpp:168-169): the 256
-  // possible quotients are computed once with the IEEE division and looked up per pixel
-  float* lut = (float*)(lds + L::LUT);
-  if constexpr (U8) lut[tid] = (float)tid / 255.0f;
 
   // A frame is fetched with wide loads, all issued before the first LDS store, one frame ahead of
   // the frame being computed (a load per loop iteration would expose one memory latency each).
@@ -128,7 +126,7 @@ __global__ __launch_bounds__(256) void ita_tokenizer_kernel(const ItaTokArgs a) 
           const int idx = 16 * p + e;
           if (idx < 5400) {
             const int y = idx / 90, x = idx - 90 * y;
-            img[(y + 3) * PW + x + 3] = lut[((unsigned)fv[j][e >> 2] >> (8 * (e & 3))) & 0xffu];
+            img[(y + 3) * PW + x + 3] = (float)(((unsigned)fv[j][e >> 2] >> (8 * (e & 3))) & 0xffu);
           }
         }
       } else {

@@ -69,7 +69,7 @@ struct ita_context {
   const float *tail_b = nullptr, *dec_w = nullptr, *dec_b = nullptr, *fc_w = nullptr, *fc_b = nullptr;
   // derived device buffers
   float* tail_wT = nullptr;
-  float* tok_wT = nullptr;                 // [50][E] conv7x7 weights k-major, row 49 = 0
+  float* tok_wT = nullptr;                 // [2][50][E] conv7x7 weights k-major, row 49 = 0; second copy x 1/65280 (u8 frames)
   float* wcat[3] = {nullptr, nullptr, nullptr};
   float* bsum[3] = {nullptr, nullptr, nullptr};
   // split-precision (f16 hi/lo) tail: folded tail+decoder matrix and LSTM weights, pre-scaled
@@ -336,7 +336,8 @@ int build_stream_image(const StreamHostParams& p, char** d_out) {
       for (int ct = 0; ct < 4; ++ct)
         for (int lane = 0; lane < 64; ++lane) {
           const int t = 4 * s + (lane >> 4), rho = lane & 15, ch = 16 * (rho >> 2) + 4 * ct + (rho & 3);
-          cw[(s * 4 + ct) * 64 + lane] = t < 49 ? p.conv_w[(size_t)ch * 49 + t] : 0.0f;
+          // scaled by 1 / (255 * 256): the kernel's blend is the exact integer 65280 * (patch value) on pixel codes
+          cw[(s * 4 + ct) * 64 + lane] = t < 49 ? p.conv_w[(size_t)ch * 49 + t] * (1.0f / 65280.0f) : 0.0f;
         }
     memcpy(im.data() + L::CB, p.conv_b, E * 4);
     int32_t* tap = (int32_t*)(im.data() + L::TAP);
@@ -466,9 +467,9 @@ bool fuse_tokenizer(const ita_context* c, int image_dtype) {
 int launch_tokenizer(ita_context* c, const void* img, int dtype, float* tokens, int B, hipStream_t s) {
   if (!c->tok_w) return fail(ITA_ERR_BAD_BLOB, "tokenizer parameters missing from the blob");
   static const int tok_dbg = getenv("ITA_TOK_DBG") ? atoi(getenv("ITA_TOK_DBG")) : 0;
-  ItaTokArgs a{img, c->tok_wT, c->tok_b, c->tok_lw, c->tok_lb, tokens, B, tok_dbg};
-  const int grid = B < 2 * c->num_cus ? B : 2 * c->num_cus;
   const bool u8 = dtype == ITA_IMAGE_U8;
+  ItaTokArgs a{img, c->tok_wT + (u8 ? (size_t)50 * c->hdr.E : 0), c->tok_b, c->tok_lw, c->tok_lb, tokens, B, tok_dbg};
+  const int grid = B < 2 * c->num_cus ? B : 2 * c->num_cus;
   if (c->hdr.E == 64) {
     if (u8) hipLaunchKernelGGL((ita_tokenizer_kernel<64, true>), dim3(grid), dim3(256), ita_tok_lds_bytes<64>(), s, a);
     else hipLaunchKernelGGL((ita_tokenizer_kernel<64, false>), dim3(grid), dim3(256), ita_tok_lds_bytes<64>(), s, a);
@@ -820,9 +821,12 @@ int ita_load_weights(ita_handle h, const void* blob, size_t nbytes) {
   }
   if (const float* cw = hptr<float>(h, "tok.conv_w")) {
     const int Ei = hdr.E;
-    std::vector<float> wT((size_t)50 * Ei, 0.0f);
+    std::vector<float> wT((size_t)100 * Ei, 0.0f);   // [0]: for f32 frames; [1]: x 1/65280 for u8 frames (integer blend)
     for (int c = 0; c < Ei; ++c)
-      for (int k = 0; k < 49; ++k) wT[(size_t)k * Ei + c] = cw[(size_t)c * 49 + k];
+      for (int k = 0; k < 49; ++k) {
+        wT[(size_t)k * Ei + c] = cw[(size_t)c * 49 + k];
+        wT[(size_t)(50 + k) * Ei + c] = cw[(size_t)c * 49 + k] * (1.0f / 65280.0f);
+      }
     HIPCHK(hipMalloc(&h->tok_wT, wT.size() * sizeof(float)));
     HIPCHK(hipMemcpy(h->tok_wT, wT.data(), wT.size() * sizeof(float), hipMemcpyHostToDevice));
   }

@@ -87,8 +87,7 @@ struct ItaStreamLds {
   static constexpr int VB4 = TAP + (TOK ? 52 * 4 : 0);          // int32 [192][4]: bv replicated (V accumulators start per COLUMN)
   static constexpr int IMAGE = VB4 + P * 16;
   // ---- built / used at run time
-  static constexpr int LUT = IMAGE;                  // f32 [256]: k / 255.0f
-  static constexpr int K = LUT + (TOK ? 1024 : 0);   // int8 [12][128][16]  fragment order
+  static constexpr int K = IMAGE;                    // int8 [12][128][16]  fragment order
   static constexpr int VT = K + S * P;               // int8 [8][192][16]   V^T, keys permuted (ita_int8_kernels.h)
   static constexpr int COLSUM = VT + P * S;          // int32 [2][192]: 128 * column sums of V, per frame parity
   static constexpr int IMG = COLSUM + 2 * P * 4;     // u8 [8 waves][9][96]: rows 2*y0-3 .. 2*y0+5 of the next frame, 3 zero columns each side
@@ -385,20 +384,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto tok_blend = [&](int ol) {
     const TokGeo g = tok_geo(ol);
     const int kq = ol >> 4;
-    const float* lut = (const float*)(lds + L::LUT);
     const uint8_t* win = (const uint8_t*)(lds + L::IMG + wave * L::IMG_WAVE) + 2 * g.x0;
     const int* tap = (const int*)(lds + L::TAP);
-    const float h1 = g.h1, h0 = 1.0f - g.h1, w1 = g.w1, w0 = 1.0f - g.w1;
-    const f32x2 w02 = {w0, w0}, w12 = {w1, w1}, h01 = {h0, h1};
+    // The weights of this fixed resize are dyadic, h = H / 8 and w = W / 32 with 0 < H1 < 8, 0 < W1 < 32 for every
+    // token, so the blend of a tap is the exact integer  256 * 255 * value = H0 W0 a + H0 W1 b + H1 W0 c + H1 W1 d
+    // on the pixel CODES (each product weight <= 7 * 31 fits a byte); 1 / 65280 is folded into the conv weights
+    // (oracle/ita_oracle.c ita_oracle_tokenizer_u8).  No k / 255 table, no float blend.
+    const unsigned H1 = (unsigned)(8.0f * g.h1) & 7u, W1 = (unsigned)(32.0f * g.w1) & 31u, H0 = 8u - H1, W0 = 32u - W1;
+    const unsigned w00 = (H0 * W0) & 255u, w01 = (H0 * W1) & 255u, w10 = (H1 * W0) & 255u, w11 = (H1 * W1) & 255u;
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the window is private to this wave
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int s = 0; s < 13; ++s) {
-      if constexpr (ITA_ABLATE & 512) { tk_pt[s] = h01.x * (float)s; continue; }
+      if constexpr (ITA_ABLATE & 512) { tk_pt[s] = (float)(w00 * s); continue; }
       const int off = tap[4 * s + kq];    // ky * 96 + kx of tap 4s + kq (0 for the pad taps 49..51: their weights are 0)
-      const f32x2 vac = {lut[win[off]], lut[win[off + 192]]}, vbd = {lut[win[off + 2]], lut[win[off + 194]]};
-      const f32x2 r = (w02 * vac + w12 * vbd) * h01;   // {h0 * (w0 a + w1 b), h1 * (w0 c + w1 d)}: the oracle's operations, two per instruction
-      tk_pt[s] = r.x + r.y;
+      const unsigned b256 = (unsigned)win[off] * w00 + (unsigned)win[off + 2] * w01 + (unsigned)win[off + 192] * w10 +
+                            (unsigned)win[off + 194] * w11;
+      tk_pt[s] = (float)b256;
     }
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) tk_acc[ct] = *(const f32x4*)(lds + L::CB + (16 * kq + 4 * ct) * 4);
@@ -473,9 +475,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       vw[j] = (i32x4){0, 0, 0, 0};
       if (p < NW) vw[j] = *(const i32x4*)(a.image + (size_t)p * 16);
     }
-    if constexpr (TOK != 0) {
-      if (tid < 256) ((float*)(lds + L::LUT))[tid] = (float)tid / 255.0f;   // the reference host's float(pixel) / 255.0f (main.cpp:168-169)
-    }
     if (tid < 2 * P) colsum[tid] = ITA_ACC_BIAS;
 #pragma unroll
     for (int j = 0; j < NTJ; ++j) {
@@ -484,7 +483,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     if constexpr (TOK != 0) {
       tok_fill(ol);
-      lds_barrier();   // tables and k/255 in place (the weights are still in flight)
+      lds_barrier();   // tables in place (the weights are still in flight)
       tok_blend(ol);
 #pragma unroll
       for (int st = 0; st < 13; ++st) tok_step(st, ol);

@@ -162,6 +162,53 @@ int ita_oracle_tokenizer(const float* img, int B, int E, const float* cw, const 
   return 0;
 }
 
+/* The tokenizer on u8 WIRE FRAMES (what the UDP host receives, main.cpp:37,166).  The reference host divides every
+ * pixel by 255.0f and the graph then convolves and resizes in f32; here the pixel codes stay integers as long as they can:
+ * the bilinear weights of this fixed 30x45 -> 8x16 resize are dyadic (multiples of 1/8 vertically, 1/32 horizontally), so
+ *     B256[tap] = H0*(W0*a + W1*b) + H1*(W0*c + W1*d),   H = 8h, W = 32w,   0 <= B256 <= 255 * 256
+ * is an EXACT integer = 256 * 255 * (blended patch value), and the 1 / (255 * 256) goes into the conv weights once:
+ *     acc = bias;  acc = fmaf((float)B256[k], w[c][k] * (1.0f / 65280.0f), acc)   k = 0..48.
+ * Same linear map as ita_oracle_tokenizer on pixel / 255.0f, with one rounding per weight instead of several per tap --
+ * closer to the exact result, and (why it exists) the blend is 4 integer multiply-adds per tap on the GPU instead of a
+ * table lookup per pixel plus 9 float operations.  The two entry points agree to ~1e-6, not bit for bit. */
+int ita_oracle_tokenizer_u8(const uint8_t* img, int B, int E, const float* cw, const float* cb, const float* lnw,
+                            const float* lnb, float* tokens) {
+  float pb[49];
+  float* pre = (float*)malloc(sizeof(float) * (size_t)E);
+  float* ws = (float*)malloc(sizeof(float) * (size_t)E * 49);
+  const float inv = 1.0f / 65280.0f;
+  for (int i = 0; i < E * 49; ++i) ws[i] = cw[i] * inv;
+  int rc = 0;
+  for (int b = 0; b < B && !rc; ++b)
+    for (int oy = 0; oy < TOK_H && !rc; ++oy)
+      for (int ox = 0; ox < TOK_W && !rc; ++ox) {
+        int y0, yp, x0, xp;
+        float ly, lx;
+        bilinear_src(oy, CONV_H, TOK_H, &y0, &yp, &ly);
+        bilinear_src(ox, CONV_W, TOK_W, &x0, &xp, &lx);
+        const float H1f = 8.0f * ly, W1f = 32.0f * lx;
+        const int H1 = (int)H1f, W1 = (int)W1f, H0 = 8 - H1, W0 = 32 - W1;
+        if ((float)H1 != H1f || (float)W1 != W1f) { rc = -3; break; }   /* the weights of this resize are dyadic */
+        const uint8_t* im = img + (size_t)b * IMG_H * IMG_W;
+        for (int ky = 0; ky < 7; ++ky)
+          for (int kx = 0; kx < 7; ++kx) {
+            const int iy = 2 * y0 - 3 + ky, ix = 2 * x0 - 3 + kx;
+#define PX_(y, x) (((y) < 0 || (y) >= IMG_H || (x) < 0 || (x) >= IMG_W) ? 0 : (int)im[(y) * IMG_W + (x)])
+            const int a = PX_(iy, ix), bb = PX_(iy, ix + 2 * xp), c = PX_(iy + 2 * yp, ix), d = PX_(iy + 2 * yp, ix + 2 * xp);
+#undef PX_
+            pb[ky * 7 + kx] = (float)(H0 * (W0 * a + W1 * bb) + H1 * (W0 * c + W1 * d));
+          }
+        for (int c = 0; c < E; ++c) {
+          float acc = cb[c];
+          for (int k = 0; k < 49; ++k) acc = fmaf(pb[k], ws[c * 49 + k], acc);
+          pre[c] = acc;
+        }
+        layernorm_row(pre, E, lnw, lnb, tokens + ((size_t)b * 128 + oy * TOK_W + ox) * E);
+      }
+  free(pre); free(ws);
+  return rc;
+}
+
 /* u8 wire frame -> f32, as the reference host does (samples/inference_udp_FPGA_custom_dispatch/
  * main.cpp:168-169: float(pixel) / 255.0f). */
 void ita_oracle_u8_to_f32(const uint8_t* in, size_t n, float* out) {
@@ -441,16 +488,19 @@ int ita_oracle_forward(const void* blob, size_t nbytes, const void* image, int i
   const int has_tail = hd->has_tail;   /* 0: models/ITA/QAT/model.py:80-81 -- the decoder reads the flattened tokens */
   const size_t tokn = (size_t)B * S * E;
   float* img = (float*)malloc(sizeof(float) * (size_t)B * IMG_H * IMG_W);
-  if (image_is_u8) ita_oracle_u8_to_f32((const uint8_t*)image, (size_t)B * IMG_H * IMG_W, img);
-  else memcpy(img, image, sizeof(float) * (size_t)B * IMG_H * IMG_W);
+  if (!image_is_u8) memcpy(img, image, sizeof(float) * (size_t)B * IMG_H * IMG_W);
   float* x = (float*)malloc(sizeof(float) * tokn);
   float* y = (float*)malloc(sizeof(float) * tokn);
   float* feat = (float*)malloc(sizeof(float) * (size_t)B * 4608);
   float* cat = (float*)malloc(sizeof(float) * (size_t)B * 517);
   float* dec = (float*)malloc(sizeof(float) * (size_t)B * 512);
   int rc = 0;
-  ita_oracle_tokenizer(img, B, E, (const float*)GET("tok.conv_w"), (const float*)GET("tok.conv_b"),
-                       (const float*)GET("tok.ln_w"), (const float*)GET("tok.ln_b"), x);
+  if (image_is_u8)
+    rc = ita_oracle_tokenizer_u8((const uint8_t*)image, B, E, (const float*)GET("tok.conv_w"), (const float*)GET("tok.conv_b"),
+                                 (const float*)GET("tok.ln_w"), (const float*)GET("tok.ln_b"), x);
+  else
+    ita_oracle_tokenizer(img, B, E, (const float*)GET("tok.conv_w"), (const float*)GET("tok.conv_b"),
+                         (const float*)GET("tok.ln_w"), (const float*)GET("tok.ln_b"), x);
   if (t_tokens) memcpy(t_tokens, x, sizeof(float) * tokn);
   char nm[32];
   for (int i = 0; i < L; ++i) {

@@ -45,6 +45,17 @@ def _c(a, dt):
 
 
 def tokenizer(img, cw, cb, lnw, lnb):
+    """f32 frames: the float blend; uint8 wire frames: the exact integer blend (ita_oracle_tokenizer_u8)"""
+    img = np.asarray(img)
+    if img.dtype == np.uint8:
+        img = np.ascontiguousarray(img).reshape(-1, 60, 90)
+        B, E = img.shape[0], cw.shape[0]
+        out = np.empty((B, 128, E), np.float32)
+        rc = lib().ita_oracle_tokenizer_u8(_p(img), B, E, _p(_c(cw, np.float32)), _p(_c(cb, np.float32)),
+                                           _p(_c(lnw, np.float32)), _p(_c(lnb, np.float32)), _p(out))
+        if rc:
+            raise RuntimeError(f"ita_oracle_tokenizer_u8 rc={rc}")
+        return out
     img = _c(img, np.float32).reshape(-1, 60, 90)
     B, E = img.shape[0], cw.shape[0]
     out = np.empty((B, 128, E), np.float32)

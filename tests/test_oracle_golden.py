@@ -185,10 +185,14 @@ def test_full_forward_two_steps(oracle, path):
     np.testing.assert_allclose(vel1, d["s1.vel"], atol=5e-4, rtol=0)
     np.testing.assert_allclose(h1, d["s1.h"], atol=5e-4, rtol=0)
     np.testing.assert_allclose(c1, d["s1.c"], atol=5e-4, rtol=0)
-    # float-image entry point gives the same result as the u8 wire entry point
+    # float-image entry point (float(pixel) / 255.0f and the float blend) against the u8 wire entry point (integer
+    # blend of the pixel codes, 1/65280 in the conv weights): the same linear map, rounded differently -- the tokens
+    # agree to 4e-6, the velocity to what the int8 blocks allow behind such a difference
     img_f = d["in0.img_u8"].astype(np.float32) / np.float32(255.0)
-    vel0f, _, _ = oracle.forward(blob, img_f, d["in0.desvel"], d["in0.quat"])
-    np.testing.assert_array_equal(vel0f, vel0)
+    vel0f, _, _, tpf = oracle.forward(blob, img_f, d["in0.desvel"], d["in0.quat"], taps=True)
+    np.testing.assert_allclose(tpf["tokens"], tp["tokens"], atol=4e-6, rtol=0)
+    np.testing.assert_allclose(tpf["tokens"], d["s0.tok.out"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(vel0f, d["s0.vel"], atol=5e-4, rtol=0)
 
 
 FIX_2L = golden_files("vit2l_*.npz")
