@@ -162,15 +162,100 @@ __global__ __launch_bounds__(64 * WM * WN) void ita_gemm_f16x3_kernel(const ItaG
     }
 }
 
-// ---- the same GEMM for small M (a few frames: the reference's real deployment is ONE drone, M = 1).
-// ita_gemm_f16x3_kernel needs M >= 1024 to fill the chip and, at M = 1, still walks its 16 k-tiles with one
-// exposed memory latency each (22 us).  Here one wave owns one 32 x 32 output tile of one K slice and streams its
-// fragments straight from L2 into an 8-slot register ring (7 k-steps in flight); grid (N/32, ceil(M/32), nsplit).
+// ---- the same GEMM for 32 < M <= 256.  ita_gemm_f16x3_kernel needs M >= 1024 to fill the chip (at 256 frames it has 64
+// workgroups).  Here a workgroup of four waves owns MT (1..4) 32-row M tiles x one 32-column
+// W tile x one K slice: wave w computes M tile w, ALL four waves issue the LDS-DMA of the next k-tiles (an LDS ring
+// of three 64-deep k-tiles).  grid.x = N/32 * nsplit with id % nsplit = the K slice (each XCD's L2 sees one
+// slice of A and of G0), grid.y = ceil(M / 128).
+// What this shape answers (all measured, 128 frames unless noted): a fragment is 16 bytes per lane at ROW r, so a
+// wave-load of fragments touches 32 cache lines for 32 bytes each and the load pipeline's per-instruction cost, not
+// bandwidth or latency, sets the pace -- one wave streaming its own tile into a register ring took 20 us whether its
+// lines were hot or cold (8 us per operand; fetching whole lines per lane pair, touching everything first or placing
+// the K slices per XCD changed nothing); the same wave with an LDS-DMA ring (8 whole lines per wave-instruction) 14 us,
+// because an LDS-DMA piece costs its issuing wave ~100 cycles.  So the issue is spread over four waves, and the W tile
+// is staged once for the M tiles that share it.
 // Per output element the arithmetic is IDENTICAL to the large kernel's -- the same v_mfma_f32_32x32x16_f16 on the
 // same operand values in the same lane slots, k-steps in the same order, the same three products per step -- so a
 // frame's result does not depend on which of the two kernels served its batch (tests: a 5-frame batch against
 // rows of a 1024-frame batch, bit for bit).
-__global__ __launch_bounds__(64) void ita_gemm_f16x3_small_kernel(const ItaGemmSplitArgs g) {
+// k-tiles in the LDS ring (4..8 where 160 KB hold them measured 1-3 % slower at every M)
+constexpr int ita_gemm_small_nstg(int mt) { return 3; }
+constexpr int ita_gemm_small_lds(int mt) { return ita_gemm_small_nstg(mt) * (2 * mt + 2) * 32 * 128; }
+constexpr int ita_waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }   // s_waitcnt vmcnt(n) only
+template <int DMA>
+__device__ __forceinline__ void wait_dma_tiles(int younger) {   // until at most `younger` k-tiles of this wave's DMA are outstanding
+  switch (younger) {
+    case 0: __builtin_amdgcn_s_waitcnt(ita_waitcnt_vm(0)); break;
+    case 1: __builtin_amdgcn_s_waitcnt(ita_waitcnt_vm(DMA)); break;
+    case 2: __builtin_amdgcn_s_waitcnt(ita_waitcnt_vm(2 * DMA)); break;
+    case 3: __builtin_amdgcn_s_waitcnt(ita_waitcnt_vm(3 * DMA < 63 ? 3 * DMA : 63)); break;
+    case 4: __builtin_amdgcn_s_waitcnt(ita_waitcnt_vm(4 * DMA < 63 ? 4 * DMA : 63)); break;
+    case 5: __builtin_amdgcn_s_waitcnt(ita_waitcnt_vm(5 * DMA < 63 ? 5 * DMA : 63)); break;
+    default: __builtin_amdgcn_s_waitcnt(ita_waitcnt_vm(6 * DMA < 63 ? 6 * DMA : 63)); break;
+  }
+}
+template <int MT>
+__global__ __launch_bounds__(256) void ita_gemm_f16x3_small_kernel(const ItaGemmSplitArgs g) {
+  constexpr int NSTG = ita_gemm_small_nstg(MT), PLANE = 32 * 128, APL = MT * PLANE, STG = 2 * APL + 2 * PLANE;
+  constexpr int DMA = 2 * MT + 2;   // LDS-DMA wave-instructions per wave and k-tile
+  static_assert(DMA * (NSTG - 1) < 64 && NSTG <= 8, "vmcnt range");
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
+  const int z = blockIdx.x % g.nsplit, n0 = (blockIdx.x / g.nsplit) * 32, m0 = blockIdx.y * 128;
+  const int kslice = g.K / g.nsplit, kbeg = z * kslice, nt = kslice / 64;
+  auto stage = [&](int kt, int slot) {
+    char* b = lds + slot * STG;
+    const int k0 = kbeg + kt * 64;
+    stage_plane<32 * MT, 256>(g.a_hi, g.lda, m0, g.M - 1, k0, b, tid);
+    stage_plane<32 * MT, 256>(g.a_lo, g.lda, m0, g.M - 1, k0, b + APL, tid);
+    stage_plane<32, 256>(g.w_hi, g.ldw, n0, g.N - 1, k0, b + 2 * APL, tid);
+    stage_plane<32, 256>(g.w_lo, g.ldw, n0, g.N - 1, k0, b + 2 * APL + PLANE, tid);
+  };
+#pragma unroll
+  for (int s = 0; s < NSTG - 1; ++s)
+    if (s < nt) stage(s, s);
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+  const bool compute = wave < MT && m0 + 32 * wave < g.M;
+  for (int kt = 0; kt < nt; ++kt) {
+    // The compiler does not track LDS-DMA, so the waits are explicit.  This wave's pieces of tile kt have landed when
+    // at most those of the younger tiles are outstanding; the barrier then says the same of every wave's pieces
+    // -- and that every wave has finished reading tile kt - 1, whose slot the next stage call refills.
+    wait_dma_tiles<DMA>(min(nt - 1 - kt, NSTG - 2));
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's fragment reads of tile kt - 1 have returned
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + NSTG - 1 < nt) stage(kt + NSTG - 1, (kt + NSTG - 1) % NSTG);
+    if (compute) {
+      const char* b = lds + (kt % NSTG) * STG;
+      const char *pah = b + wave * PLANE, *pal = b + APL + wave * PLANE, *pwh = b + 2 * APL, *pwl = pwh + PLANE;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const f16x8 ah = frag_f16(pah, r, 2 * ks + h), al = frag_f16(pal, r, 2 * ks + h);
+        const f16x8 wh = frag_f16(pwh, r, 2 * ks + h), wl = frag_f16(pwl, r, 2 * ks + h);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, acc, 0, 0, 0);
+      }
+    }
+  }
+  if (!compute) return;
+  // C layout: col n = lane&31, row m = (e&3) + 8*(e>>2) + 4*h
+  float* out = g.out + (size_t)z * g.M * g.N;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int m = m0 + 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * h;
+    if (m < g.M) out[(size_t)m * g.N + n0 + r] = acc[e];
+  }
+}
+
+// ---- and for M <= 32 (one M tile: the single-drone deployment): one wave per 32 x 32 output tile and K slice streams
+// its fragments straight from L2 into an 8-slot register ring (7 k-steps in flight); grid (N/32, 1, nsplit).  With a
+// single M tile nothing is shared inside a workgroup, and the barrier per k-tile of the kernel above costs more than
+// the row-strided loads it avoids (M = 1: 5 us here, 8 us there).  Same arithmetic per output element again.
+__global__ __launch_bounds__(64) void ita_gemm_f16x3_tiny_kernel(const ItaGemmSplitArgs g) {
   const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
   const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32, z = blockIdx.z;
   const int kslice = g.K / g.nsplit, kbeg = z * kslice, nstep = kslice / 16;

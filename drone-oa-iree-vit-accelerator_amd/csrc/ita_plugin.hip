@@ -539,9 +539,21 @@ int launch_gemm_split(const _Float16* a_hi, const _Float16* a_lo, int lda, const
   if (N % BN || K % (64 * nsplit)) return fail(ITA_ERR_UNSUPPORTED, "split gemm shape");
   static const int dbg = getenv("ITA_GEMM_DBG") ? atoi(getenv("ITA_GEMM_DBG")) : 0;
   ItaGemmSplitArgs g{a_hi, a_lo, lda, w_hi, w_lo, ldw, out, M, N, K, nsplit, dbg};
-  static const int small_max = getenv("ITA_GEMM_SMALL_MAX") ? atoi(getenv("ITA_GEMM_SMALL_MAX")) : 128;
-  if (M <= small_max && N % 32 == 0) {   // a few frames: one wave per 32 x 32 tile and K slice, same arithmetic
-    hipLaunchKernelGGL(ita_gemm_f16x3_small_kernel, dim3(N / 32, (M + 31) / 32, nsplit), dim3(64), 0, s, g);
+  static const int small_max = getenv("ITA_GEMM_SMALL_MAX") ? atoi(getenv("ITA_GEMM_SMALL_MAX")) : 256;
+  static const int tiny_max = getenv("ITA_GEMM_TINY_MAX") ? atoi(getenv("ITA_GEMM_TINY_MAX")) : 32;
+  if (M <= tiny_max && M <= 32 && N % 32 == 0) {   // one M tile: one wave per 32 x 32 tile and K slice
+    hipLaunchKernelGGL(ita_gemm_f16x3_tiny_kernel, dim3(N / 32, 1, nsplit), dim3(64), 0, s, g);
+    HIPCHK(hipGetLastError());
+    return ITA_OK;
+  }
+  if (M <= small_max && N % 32 == 0) {   // a few M tiles: four-wave workgroups share the staging, same arithmetic
+    const dim3 grid((N / 32) * nsplit, (M + 127) / 128);
+    switch (M >= 128 ? 4 : (M + 31) / 32) {
+      case 1: hipLaunchKernelGGL(ita_gemm_f16x3_small_kernel<1>, grid, dim3(256), ita_gemm_small_lds(1), s, g); break;
+      case 2: hipLaunchKernelGGL(ita_gemm_f16x3_small_kernel<2>, grid, dim3(256), ita_gemm_small_lds(2), s, g); break;
+      case 3: hipLaunchKernelGGL(ita_gemm_f16x3_small_kernel<3>, grid, dim3(256), ita_gemm_small_lds(3), s, g); break;
+      default: hipLaunchKernelGGL(ita_gemm_f16x3_small_kernel<4>, grid, dim3(256), ita_gemm_small_lds(4), s, g); break;
+    }
     HIPCHK(hipGetLastError());
     return ITA_OK;
   }
@@ -705,6 +717,10 @@ int ita_create(ita_handle* out, int device_ordinal) {
     auto k1 = ita_gemm_f16x3_kernel<128, 128, 2, 4>;
     constexpr int b1 = ItaGemmSplitLds<128, 128>::TOTAL;
     if ((rc = set_lds(k1, b1))) { delete c; return rc; }
+    if ((rc = set_lds(ita_gemm_f16x3_small_kernel<1>, ita_gemm_small_lds(1)))) { delete c; return rc; }
+    if ((rc = set_lds(ita_gemm_f16x3_small_kernel<2>, ita_gemm_small_lds(2)))) { delete c; return rc; }
+    if ((rc = set_lds(ita_gemm_f16x3_small_kernel<3>, ita_gemm_small_lds(3)))) { delete c; return rc; }
+    if ((rc = set_lds(ita_gemm_f16x3_small_kernel<4>, ita_gemm_small_lds(4)))) { delete c; return rc; }
   }
   *out = c;
   return ITA_OK;
