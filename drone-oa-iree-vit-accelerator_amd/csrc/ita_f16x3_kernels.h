@@ -301,15 +301,23 @@ __global__ __launch_bounds__(64) void ita_gemm_f16x3_tiny_kernel(const ItaGemmSp
 // sums the partials in a fixed order, and performs the cell update.
 // One wave per workgroup = 32 frames x 8 units; grid (16, ceil(B/32)); every load is issued before the
 // first MFMA.
+// The [x | h] operand planes of LSTM layers 1, 2 (K = 256, f16 hi and lo) live in FRAGMENT order: the 32x32x16 B fragment
+// of frame tile fg, k-range kw (64 k, one per wave of ita_lstm_layer_kernel) and k-step s is 64 lanes x 16 bytes
+// contiguous, lane (r = frame & 31, h) holding k = 64 kw + 16 s + 8 h .. + 7.  Row-major planes made every fragment
+// load touch 32 cache lines for 32 bytes each (and every epilogue store 32 lines for 2 bytes each); the load pipeline's
+// per-line cost, not bandwidth, is what these small kernels wait for.  Rows are padded to whole 32-frame tiles.
+__device__ __forceinline__ size_t ita_lstm_plane_index(int b, int k) {
+  return ((size_t)(((b >> 5) * 4 + (k >> 6)) * 4 + ((k >> 4) & 3)) * 64 + ((k >> 3) & 1) * 32 + (b & 31)) * 8 + (k & 7);
+}
 struct ItaLstm0Args {
   const float* part; int nsplit; float inv_fold_scale;   // [nsplit][B][512] raw accumulators of x2 . (G0 * scale)^T
-  const _Float16 *w_hi, *w_lo; float inv_wscale;         // [512][144] permuted rows, pre-scaled: [W_hh0 | w_dv | w_quat | 0]
+  const _Float16 *w_hi, *w_lo; float inv_wscale;         // [ut 16][k-step 9][lane 64][8] A fragments of the permuted, pre-scaled [W_hh0 | w_dv | w_quat | 0]
   const float* bias;                                     // [512] gate-major: W_ih0[:, :512].bias' + b_ih0 + b_hh0
   const float *desvel, *quat;                            // (B), (B,4)
   const float* h_in;                                     // (B,128) layer-0 hidden state STAGED by frame index
   const float* c_in;                                     // layer-0 cell state rows (slot- or frame-indexed)
   float *h_out, *c_out;
-  _Float16 *nx_hi, *nx_lo; const float* nx_h_in;         // layer 1 planes [B][256] = [h_out | h_in1]
+  _Float16 *nx_hi, *nx_lo; const float* nx_h_in;         // layer 1 operand planes [h_out | h_in1] in fragment order (ita_lstm_plane_index)
   int B;
   const int* slots;
 };
@@ -332,8 +340,8 @@ __global__ __launch_bounds__(64) void ita_lstm0_kernel(const ItaLstm0Args a) {
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-  const _Float16* wrow_hi = a.w_hi + (size_t)(ut * 32 + r) * 144 + 8 * h;
-  const _Float16* wrow_lo = a.w_lo + (size_t)(ut * 32 + r) * 144 + 8 * h;
+  const _Float16* wfr_hi = a.w_hi + ((size_t)ut * 9 * 64 + lane) * 8;   // fragment order: 1 KB per wave-load
+  const _Float16* wfr_lo = a.w_lo + ((size_t)ut * 9 * 64 + lane) * 8;
   const float* hrow = a.h_in + (size_t)bc * 128 + 8 * h;
   f32x4 xa[9][2];
   f16x8 wh[9], wl[9];
@@ -351,8 +359,8 @@ __global__ __launch_bounds__(64) void ita_lstm0_kernel(const ItaLstm0Args a) {
         xa[s][1].x = q.w;
       }
     }
-    wh[s] = *(const f16x8*)(wrow_hi + 16 * s);
-    wl[s] = *(const f16x8*)(wrow_lo + 16 * s);
+    wh[s] = *(const f16x8*)(wfr_hi + s * 512);
+    wl[s] = *(const f16x8*)(wfr_lo + s * 512);
   }
   // epilogue operands too: everything this lane will ever read is in flight before the first wait
   const f32x4 ci = *(const f32x4*)(a.c_in + sb * 128 + u0);
@@ -402,10 +410,11 @@ __global__ __launch_bounds__(64) void ita_lstm0_kernel(const ItaLstm0Args a) {
     split_f16(hn[q], x, y); h_hi[q] = x; h_lo[q] = y;
     split_f16(nh[q], x, y); n_hi[q] = x; n_lo[q] = y;
   }
-  *(f16x4*)(a.nx_hi + (size_t)b * 256 + u0) = h_hi;
-  *(f16x4*)(a.nx_lo + (size_t)b * 256 + u0) = h_lo;
-  *(f16x4*)(a.nx_hi + (size_t)b * 256 + 128 + u0) = n_hi;
-  *(f16x4*)(a.nx_lo + (size_t)b * 256 + 128 + u0) = n_lo;
+  const size_t o0 = ita_lstm_plane_index(b, u0), o1 = ita_lstm_plane_index(b, 128 + u0);   // 32 lanes x 16 B contiguous
+  *(f16x4*)(a.nx_hi + o0) = h_hi;
+  *(f16x4*)(a.nx_lo + o0) = h_lo;
+  *(f16x4*)(a.nx_hi + o1) = n_hi;
+  *(f16x4*)(a.nx_lo + o1) = n_lo;
 }
 
 // ------------------------------------------------------------------ one LSTM layer per launch
@@ -416,8 +425,8 @@ __global__ __launch_bounds__(64) void ita_lstm0_kernel(const ItaLstm0Args a) {
 // (row = (e&3) + 8*(e>>2) + 4*h) puts all four gates of a (frame, unit) pair in ONE lane:
 // e>>2 is the gate, (e&3) + 4*h the unit -- the cell update needs no cross-lane traffic.
 struct ItaLstmLayerArgs {
-  const _Float16 *a_hi, *a_lo; int lda;   // [B][K] input planes  [x | h_in]
-  const _Float16 *w_hi, *w_lo; int ldw;   // [512][K] permuted rows, pre-scaled
+  const _Float16 *a_hi, *a_lo; int lda;   // input planes [x | h_in] in fragment order (ita_lstm_plane_index); lda unused
+  const _Float16 *w_hi, *w_lo; int ldw;   // [ut 16][k-range 4][k-step 4][lane 64][8] A fragments of the permuted, pre-scaled rows; ldw unused
   float inv_wscale;
   const float* bsum;      // [512] b_ih + b_hh, original gate-major order
   const float* c_in;      // (B,128)
@@ -437,16 +446,17 @@ __global__ __launch_bounds__(256) void ita_lstm_layer_kernel(const ItaLstmLayerA
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ut = blockIdx.x, f0 = blockIdx.y * 32;
   const int r = lane & 31, h = lane >> 5;
+  static_assert(NK == 4, "fragment-order operands: four k-ranges of four k-steps (K = 256)");
   const int arow = min(f0 + r, a.B - 1);
-  const size_t ao = (size_t)arow * a.lda + wave * NK * 16 + 8 * h;
-  const size_t wo = (size_t)(ut * 32 + r) * a.ldw + wave * NK * 16 + 8 * h;
+  const size_t ao = ((size_t)((blockIdx.y * 4 + wave) * 4) * 64 + lane) * 8;   // 1 KB per wave-load, both operands
+  const size_t wo = ((size_t)((ut * 4 + wave) * 4) * 64 + lane) * 8;
   f16x8 fah[NK], fal[NK], fwh[NK], fwl[NK];
 #pragma unroll
   for (int s = 0; s < NK; ++s) {
-    fwh[s] = *(const f16x8*)(a.w_hi + wo + 16 * s);
-    fah[s] = *(const f16x8*)(a.a_hi + ao + 16 * s);
-    fwl[s] = *(const f16x8*)(a.w_lo + wo + 16 * s);
-    fal[s] = *(const f16x8*)(a.a_lo + ao + 16 * s);
+    fwh[s] = *(const f16x8*)(a.w_hi + wo + 512 * s);
+    fah[s] = *(const f16x8*)(a.a_hi + ao + 512 * s);
+    fwl[s] = *(const f16x8*)(a.w_lo + wo + 512 * s);
+    fal[s] = *(const f16x8*)(a.a_lo + ao + 512 * s);
   }
   // epilogue operands of this lane's (frame, unit) as well: wave q finishes unit (4h + q) of frame r
   const int q = wave, b = f0 + r, u = ut * 8 + 4 * h + q;
@@ -484,12 +494,13 @@ __global__ __launch_bounds__(256) void ita_lstm_layer_kernel(const ItaLstmLayerA
   a.h_out[sb * 128 + u] = hn;
   if (a.nx_hi) {
     _Float16 x, y;
+    const size_t o0 = ita_lstm_plane_index(b, u), o1 = ita_lstm_plane_index(b, 128 + u);
     split_f16(hn, x, y);
-    a.nx_hi[(size_t)b * 256 + u] = x;
-    a.nx_lo[(size_t)b * 256 + u] = y;
+    a.nx_hi[o0] = x;
+    a.nx_lo[o0] = y;
     split_f16(nx_prev, x, y);
-    a.nx_hi[(size_t)b * 256 + 128 + u] = x;
-    a.nx_lo[(size_t)b * 256 + 128 + u] = y;
+    a.nx_hi[o1] = x;
+    a.nx_lo[o1] = y;
   }
 }
 

@@ -196,10 +196,10 @@ int ensure_workspace(ita_context* c, int B, hipStream_t s = nullptr) {
   HIPCHK(hipMalloc(&c->gates, sizeof(float) * (size_t)B * 512));
   HIPCHK(hipMalloc(&c->x2_hi, 2 * (size_t)B * c->ldfold));
   HIPCHK(hipMalloc(&c->x2_lo, 2 * (size_t)B * c->ldfold));
-  HIPCHK(hipMalloc(&c->c1_hi, 2 * (size_t)B * 256));
-  HIPCHK(hipMalloc(&c->c1_lo, 2 * (size_t)B * 256));
-  HIPCHK(hipMalloc(&c->c2_hi, 2 * (size_t)B * 256));
-  HIPCHK(hipMalloc(&c->c2_lo, 2 * (size_t)B * 256));
+  HIPCHK(hipMalloc(&c->c1_hi, 2 * (size_t)((B + 31) / 32 * 32) * 256));   // fragment order, whole 32-frame tiles
+  HIPCHK(hipMalloc(&c->c1_lo, 2 * (size_t)((B + 31) / 32 * 32) * 256));   // fragment order, whole 32-frame tiles
+  HIPCHK(hipMalloc(&c->c2_hi, 2 * (size_t)((B + 31) / 32 * 32) * 256));   // fragment order, whole 32-frame tiles
+  HIPCHK(hipMalloc(&c->c2_lo, 2 * (size_t)((B + 31) / 32 * 32) * 256));   // fragment order, whole 32-frame tiles
   HIPCHK(hipMalloc(&c->part, 2 * sizeof(float) * (size_t)NSPLIT * B * 512));   // two buffers: ita_vitlstm_front/back
   c->cap = B;
   return ITA_OK;
@@ -889,7 +889,17 @@ int ita_load_weights(ita_handle h, const void* blob, size_t nbytes) {
           memcpy(&wf[(size_t)rp * kf], &wc[(size_t)j * kp], sizeof(float) * 256);
         }
       }
-      int rc2 = split_upload(wf, &h->lw_hi[l], &h->lw_lo[l], &h->lw_inv_scale[l]);
+      // ... and stored as the A fragments the LSTM kernels load: [ut][k-range][k-step][lane (row r, k half h)][8]
+      const int nsw = l == 0 ? 1 : 4, nss = l == 0 ? kf / 16 : 4;   // k-ranges (one per wave) x k-steps of 16
+      std::vector<float> wfrag(wf.size());
+      for (int ut = 0; ut < 16; ++ut)
+        for (int kw = 0; kw < nsw; ++kw)
+          for (int st = 0; st < nss; ++st)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int j = 0; j < 8; ++j)
+                wfrag[((((size_t)ut * nsw + kw) * nss + st) * 64 + lane) * 8 + j] =
+                    wf[(size_t)(ut * 32 + (lane & 31)) * kf + (kw * nss + st) * 16 + 8 * (lane >> 5) + j];
+      int rc2 = split_upload(wfrag, &h->lw_hi[l], &h->lw_lo[l], &h->lw_inv_scale[l]);
       if (rc2) { free_weights(h); return rc2; }
     }
   }
