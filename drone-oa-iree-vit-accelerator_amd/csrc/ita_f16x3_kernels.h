@@ -309,6 +309,15 @@ __global__ __launch_bounds__(64) void ita_gemm_f16x3_tiny_kernel(const ItaGemmSp
 __device__ __forceinline__ size_t ita_lstm_plane_index(int b, int k) {
   return ((size_t)(((b >> 5) * 4 + (k >> 6)) * 4 + ((k >> 4) & 3)) * 64 + ((k >> 3) & 1) * 32 + (b & 31)) * 8 + (k & 7);
 }
+// Gate non-linearities of the f16x3 path: v_exp_f32 / v_rcp_f32 forms (1 ulp each, ~6 instructions instead of ~28 for
+// the oracle's fixed-arithmetic expf + IEEE division).  This path's tolerance against the f32 oracle is 2e-5 (measured
+// max |vel - oracle| stays <= 4e-6); the exact-f32 path (tail mode 0) keeps ita_sigmoid / ita_tanh.
+__device__ __forceinline__ float lstm_sigmoid_fast(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
+}
+__device__ __forceinline__ float lstm_tanh_fast(float x) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * 2.88539008177792681f) + 1.0f);
+}
 struct ItaLstm0Args {
   const float* part; int nsplit; float inv_fold_scale;   // [nsplit][B][512] raw accumulators of x2 . (G0 * scale)^T
   const _Float16 *w_hi, *w_lo; float inv_wscale;         // [ut 16][k-step 9][lane 64][8] A fragments of the permuted, pre-scaled [W_hh0 | w_dv | w_quat | 0]
@@ -323,44 +332,47 @@ struct ItaLstm0Args {
 };
 template <int NS>
 __global__ __launch_bounds__(64) void ita_lstm0_kernel(const ItaLstm0Args a) {
+  // Every global load below is laid out so that a wave-load covers whole cache lines (8 lines of 128 B, not 32 lines for
+  // 32 bytes each): the partials and the h rows are fetched row-wise and turned to the MFMA layouts through LDS.
+  __shared__ __attribute__((aligned(16))) float hs[32][132];   // h_in rows of the 32 frames
+  __shared__ __attribute__((aligned(16))) float pt[32][36];    // this tile's summed split-K partials [frame][gate * 8 + unit]
   const int lane = threadIdx.x;
   const int ut = blockIdx.x, r = lane & 31, h = lane >> 5;
-  const int b = blockIdx.y * 32 + r;
+  const int f0 = blockIdx.y * 32;
+  const int b = f0 + r;
   const int bc = min(b, a.B - 1);
   const size_t sb = a.slots ? (size_t)a.slots[bc] : (size_t)bc;
-  // split-K partials of this lane's 16 gate values: issue all loads first
   const int u0 = ut * 8 + 4 * h;
+  // split-K partials: load i covers frames 8i .. 8i+7, lane (frame 8i + lane/8, columns 4 (lane % 8) ..)
   f32x4 pz[NS][4];
 #pragma unroll
   for (int z = 0; z < NS; ++z)
 #pragma unroll
-    for (int gt = 0; gt < 4; ++gt)
-      pz[z][gt] = *(const f32x4*)(a.part + ((size_t)z * a.B + bc) * 512 + ut * 32 + gt * 8 + 4 * h);
+    for (int i = 0; i < 4; ++i)
+      pz[z][i] = *(const f32x4*)(a.part + ((size_t)z * a.B + min(f0 + 8 * i + (lane >> 3), a.B - 1)) * 512 + ut * 32 + 4 * (lane & 7));
+  // h rows: load i covers frames 2i, 2i+1
+  f32x4 hv[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    hv[i] = *(const f32x4*)(a.h_in + (size_t)min(f0 + 2 * i + h, a.B - 1) * 128 + 4 * r);
   // small GEMM: A operand = weights (rows = permuted gates), B operand = this frame's [h | dv | quat]
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
   const _Float16* wfr_hi = a.w_hi + ((size_t)ut * 9 * 64 + lane) * 8;   // fragment order: 1 KB per wave-load
   const _Float16* wfr_lo = a.w_lo + ((size_t)ut * 9 * 64 + lane) * 8;
-  const float* hrow = a.h_in + (size_t)bc * 128 + 8 * h;
-  f32x4 xa[9][2];
   f16x8 wh[9], wl[9];
 #pragma unroll
   for (int s = 0; s < 9; ++s) {
-    if (s < 8) {
-      xa[s][0] = *(const f32x4*)(hrow + 16 * s);
-      xa[s][1] = *(const f32x4*)(hrow + 16 * s + 4);
-    } else {
-      xa[s][0] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-      xa[s][1] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-      if (h == 0) {
-        const f32x4 q = *(const f32x4*)(a.quat + (size_t)bc * 4);
-        xa[s][0] = (f32x4){a.desvel[bc] / 10.0f, q.x, q.y, q.z};
-        xa[s][1].x = q.w;
-      }
-    }
     wh[s] = *(const f16x8*)(wfr_hi + s * 512);
     wl[s] = *(const f16x8*)(wfr_lo + s * 512);
+  }
+  f32x4 xlast0 = {0.0f, 0.0f, 0.0f, 0.0f};
+  float xlast1 = 0.0f;
+  if (h == 0) {
+    const f32x4 q = *(const f32x4*)(a.quat + (size_t)bc * 4);
+    xlast0 = (f32x4){a.desvel[bc] / 10.0f, q.x, q.y, q.z};
+    xlast1 = q.w;
   }
   // epilogue operands too: everything this lane will ever read is in flight before the first wait
   const f32x4 ci = *(const f32x4*)(a.c_in + sb * 128 + u0);
@@ -369,12 +381,28 @@ __global__ __launch_bounds__(64) void ita_lstm0_kernel(const ItaLstm0Args a) {
 #pragma unroll
   for (int gt = 0; gt < 4; ++gt) bz[gt] = *(const f32x4*)(a.bias + gt * 128 + u0);
   __builtin_amdgcn_sched_barrier(0);
+  // partials summed in their fixed order (elementwise, so the layout does not matter), then to LDS with the h rows
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f32x4 ps = pz[0][i];
+#pragma unroll
+    for (int z = 1; z < NS; ++z) ps += pz[z][i];
+    *(f32x4*)&pt[8 * i + (lane >> 3)][4 * (lane & 7)] = ps;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) *(f32x4*)&hs[2 * i + h][4 * r] = hv[i];
+  __syncthreads();
 #pragma unroll
   for (int s = 0; s < 9; ++s) {
+    f32x4 x0 = xlast0, x1 = {xlast1, 0.0f, 0.0f, 0.0f};
+    if (s < 8) {
+      x0 = *(const f32x4*)&hs[r][16 * s + 8 * h];
+      x1 = *(const f32x4*)&hs[r][16 * s + 8 * h + 4];
+    }
     f16x8 xh, xl;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float x = xa[s][j >> 2][j & 3];
+      const float x = j < 4 ? x0[j & 3] : x1[j & 3];
       const _Float16 hi = (_Float16)x;
       xh[j] = hi;
       xl[j] = (_Float16)(x - (float)hi);
@@ -390,16 +418,12 @@ __global__ __launch_bounds__(64) void ita_lstm0_kernel(const ItaLstm0Args a) {
   for (int q = 0; q < 4; ++q) {
     float g[4];
 #pragma unroll
-    for (int gt = 0; gt < 4; ++gt) {
-      float ps = pz[0][gt][q];
-#pragma unroll
-      for (int z = 1; z < NS; ++z) ps += pz[z][gt][q];
-      g[gt] = (ps * a.inv_fold_scale + acc[4 * gt + q] * a.inv_wscale) + bz[gt][q];
-    }
-    const float ig = ita_sigmoid(g[0]), fg = ita_sigmoid(g[1]), cg = ita_tanh(g[2]), og = ita_sigmoid(g[3]);
+    for (int gt = 0; gt < 4; ++gt)
+      g[gt] = (pt[r][gt * 8 + 4 * h + q] * a.inv_fold_scale + acc[4 * gt + q] * a.inv_wscale) + bz[gt][q];
+    const float ig = lstm_sigmoid_fast(g[0]), fg = lstm_sigmoid_fast(g[1]), cg = lstm_tanh_fast(g[2]), og = lstm_sigmoid_fast(g[3]);
     const float c = fmaf(fg, ci[q], ig * cg);
     cn[q] = c;
-    hn[q] = og * ita_tanh(c);
+    hn[q] = og * lstm_tanh_fast(c);
   }
   *(f32x4*)(a.c_out + sb * 128 + u0) = cn;
   *(f32x4*)(a.h_out + sb * 128 + u0) = hn;
@@ -487,9 +511,9 @@ __global__ __launch_bounds__(256) void ita_lstm_layer_kernel(const ItaLstmLayerA
   }
   const float gi = gsum[0] * a.inv_wscale + b_i, gf = gsum[1] * a.inv_wscale + b_f,
               gg = gsum[2] * a.inv_wscale + b_g, go = gsum[3] * a.inv_wscale + b_o;
-  const float ig = ita_sigmoid(gi), fg = ita_sigmoid(gf), cg = ita_tanh(gg), og = ita_sigmoid(go);
+  const float ig = lstm_sigmoid_fast(gi), fg = lstm_sigmoid_fast(gf), cg = lstm_tanh_fast(gg), og = lstm_sigmoid_fast(go);
   const float c = fmaf(fg, c_prev, ig * cg);
-  const float hn = og * ita_tanh(c);
+  const float hn = og * lstm_tanh_fast(c);
   a.c_out[sb * 128 + u] = c;
   a.h_out[sb * 128 + u] = hn;
   if (a.nx_hi) {
