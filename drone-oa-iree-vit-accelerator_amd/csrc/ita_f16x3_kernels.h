@@ -38,6 +38,7 @@ struct ItaGemmSplitArgs {
   int M, N, K;                            // K % (64 * nsplit) == 0, N % BN == 0
   int nsplit;
   int dbg;                                // diagnostic: 1 = stage only (no MFMA), 2 = MFMA only (stage once)
+  const _Float16 *wf_hi, *wf_lo;          // the same weights as MFMA A... B fragments, [N / 32][K / 16][lane 64][8] (tiny kernel only)
 };
 
 // LDS image of one operand plane for one 64-deep K tile: row-major 128-byte rows, the eight
@@ -260,14 +261,17 @@ __global__ __launch_bounds__(64) void ita_gemm_f16x3_tiny_kernel(const ItaGemmSp
   const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32, z = blockIdx.z;
   const int kslice = g.K / g.nsplit, kbeg = z * kslice, nstep = kslice / 16;
   const size_t ao = (size_t)min(m0 + r, g.M - 1) * g.lda + kbeg + 8 * h;
-  const size_t wo = (size_t)(n0 + r) * g.ldw + kbeg + 8 * h;
+  // W comes from its fragment-order copy: 1 KB contiguous per wave-load.  From the row-major matrix a fragment load
+  // touches 32 cache lines for 32 bytes each, which one CU pulls 4-6x slower (tools/microbench/cu_fill_rows.hip);
+  // A keeps its row-major planes -- at M = 1 all its lanes read the same row.
+  const size_t wo = (((size_t)blockIdx.x * (g.K / 16) + kbeg / 16) * 64 + lane) * 8;
   constexpr int R = 8;
   f16x8 ah[R], al[R], wh[R], wl[R];
   auto fetch = [&](int s, int slot) {
     ah[slot] = *(const f16x8*)(g.a_hi + ao + 16 * s);
     al[slot] = *(const f16x8*)(g.a_lo + ao + 16 * s);
-    wh[slot] = *(const f16x8*)(g.w_hi + wo + 16 * s);
-    wl[slot] = *(const f16x8*)(g.w_lo + wo + 16 * s);
+    wh[slot] = *(const f16x8*)(g.wf_hi + wo + (size_t)s * 512);
+    wl[slot] = *(const f16x8*)(g.wf_lo + wo + (size_t)s * 512);
   };
 #pragma unroll
   for (int s = 0; s < R; ++s) fetch(s, s);

@@ -76,6 +76,7 @@ struct ita_context {
   int kfold = 8192, ldfold = 8192 + 64;    // K and plane row stride of the folded GEMM (see the constants above)
   int tail_mode = 1;                       // 1: folded f16x3 GEMMs (default), 0: exact f32 kernels
   bool folded = false;
+  _Float16 *foldf_hi = nullptr, *foldf_lo = nullptr;   // G0 once more as B... MFMA fragments [16][K/16][64][8], for batches of <= 32 frames
   _Float16 *fold_hi = nullptr, *fold_lo = nullptr;   // [512][LDFOLD]: G0 = W_ih0[:, :512] . Wfold, rows in permuted gate order
   float* fold_bias = nullptr;                        // [512] gate-major: W_ih0[:, :512] . dec(tail(0)) + b_ih0 + b_hh0
   float fold_inv_scale = 1.0f;
@@ -145,11 +146,11 @@ void free_weights(ita_context* c) {
     if (c->bsum[l]) (void)hipFree(c->bsum[l]);
     c->wcat[l] = c->bsum[l] = nullptr;
   }
-  void* extra[] = {c->fold_hi, c->fold_lo, c->fold_bias, c->lw_hi[0], c->lw_lo[0], c->lw_hi[1], c->lw_lo[1],
+  void* extra[] = {c->foldf_hi, c->foldf_lo, c->fold_hi, c->fold_lo, c->fold_bias, c->lw_hi[0], c->lw_lo[0], c->lw_hi[1], c->lw_lo[1],
                    c->lw_hi[2], c->lw_lo[2]};
   for (void* q : extra)
     if (q) (void)hipFree(q);
-  c->fold_hi = c->fold_lo = nullptr;
+  c->fold_hi = c->fold_lo = c->foldf_hi = c->foldf_lo = nullptr;
   c->fold_bias = nullptr;
   for (int l = 0; l < 3; ++l) c->lw_hi[l] = c->lw_lo[l] = nullptr;
   c->folded = false;
@@ -535,13 +536,14 @@ int launch_tail_big(ita_context* c, const ItaTailBigArgs& a, hipStream_t s) {
 
 template <int BM, int BN, int WM, int WN>
 int launch_gemm_split(const _Float16* a_hi, const _Float16* a_lo, int lda, const _Float16* w_hi, const _Float16* w_lo,
-                      int ldw, float* out, int M, int N, int K, int nsplit, hipStream_t s) {
+                      int ldw, float* out, int M, int N, int K, int nsplit, hipStream_t s, const _Float16* wf_hi = nullptr,
+                      const _Float16* wf_lo = nullptr) {
   if (N % BN || K % (64 * nsplit)) return fail(ITA_ERR_UNSUPPORTED, "split gemm shape");
   static const int dbg = getenv("ITA_GEMM_DBG") ? atoi(getenv("ITA_GEMM_DBG")) : 0;
-  ItaGemmSplitArgs g{a_hi, a_lo, lda, w_hi, w_lo, ldw, out, M, N, K, nsplit, dbg};
+  ItaGemmSplitArgs g{a_hi, a_lo, lda, w_hi, w_lo, ldw, out, M, N, K, nsplit, dbg, wf_hi, wf_lo};
   static const int small_max = getenv("ITA_GEMM_SMALL_MAX") ? atoi(getenv("ITA_GEMM_SMALL_MAX")) : 256;
   static const int tiny_max = getenv("ITA_GEMM_TINY_MAX") ? atoi(getenv("ITA_GEMM_TINY_MAX")) : 32;
-  if (M <= tiny_max && M <= 32 && N % 32 == 0) {   // one M tile: one wave per 32 x 32 tile and K slice
+  if (M <= tiny_max && M <= 32 && N % 32 == 0 && wf_hi && wf_lo) {   // one M tile: one wave per 32 x 32 tile and K slice
     hipLaunchKernelGGL(ita_gemm_f16x3_tiny_kernel, dim3(N / 32, 1, nsplit), dim3(64), 0, s, g);
     HIPCHK(hipGetLastError());
     return ITA_OK;
@@ -657,6 +659,19 @@ int build_fold(ita_context* c) {
     for (int k = 0; k < KFOLD; ++k) wf[(size_t)rp * LDFOLD + k] = hmt[(size_t)k * 512 + j];
   }
   if ((rc = split_upload(wf, &c->fold_hi, &c->fold_lo, &c->fold_inv_scale))) return rc;
+  {
+    // the same values in fragment order for ita_gemm_f16x3_tiny_kernel (same scale: max |w| is the same)
+    std::vector<float> wfr((size_t)512 * KFOLD);
+    for (int nt = 0; nt < 16; ++nt)
+      for (int st = 0; st < KFOLD / 16; ++st)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j)
+            wfr[(((size_t)nt * (KFOLD / 16) + st) * 64 + lane) * 8 + j] =
+                wf[(size_t)(nt * 32 + (lane & 31)) * LDFOLD + st * 16 + 8 * (lane >> 5) + j];
+    float inv2 = 0.0f;
+    if ((rc = split_upload(wfr, &c->foldf_hi, &c->foldf_lo, &inv2))) return rc;
+    if (inv2 != c->fold_inv_scale) return fail(ITA_ERR_UNSUPPORTED, "fragment copy of the folded weights got a different scale");
+  }
   // bias'' = W_ih0[:, :512] . bias' + b_ih0 + b_hh0   (gate-major order)
   const float *wih0 = hptr<float>(c, "lstm.w_ih0"), *bih0 = hptr<float>(c, "lstm.b_ih0"), *bhh0 = hptr<float>(c, "lstm.b_hh0");
   std::vector<float> b2(512);
@@ -1143,7 +1158,7 @@ static int forward_impl(ita_handle h, const void* image, int image_dtype, const 
   if (fast) {
     // folded tail+decoder: dec = x2 . Wfold^T + bias'   (x2 planes were written by the last FFN)
     if ((rc = launch_gemm_split<128, 128, 2, 4>(h->x2_hi, h->x2_lo, h->ldfold, h->fold_hi, h->fold_lo, h->ldfold, h->part, B,
-                                                512, h->kfold, NSPLIT, s))) return rc;
+                                                512, h->kfold, NSPLIT, s, h->foldf_hi, h->foldf_lo))) return rc;
     MARK();
     MARK();
     _Float16* chi[3] = {nullptr, h->c1_hi, h->c2_hi};
@@ -1257,7 +1272,7 @@ static int front_impl(ita_handle h, const void* image, int image_dtype, int batc
   if (encoder_done_event) HIPCHK(hipEventRecord((hipEvent_t)encoder_done_event, s));
   float* part = h->part + (size_t)buf * NSPLIT * h->cap * 512;
   if ((rc = launch_gemm_split<128, 128, 2, 4>(h->x2_hi, h->x2_lo, h->ldfold, h->fold_hi, h->fold_lo, h->ldfold, part, batch, 512,
-                                              h->kfold, NSPLIT, s))) return rc;
+                                              h->kfold, NSPLIT, s, h->foldf_hi, h->foldf_lo))) return rc;
   if ((rc = mark(3, true))) return rc;
   if (ev && (h->prof_stage == 0 || h->prof_stage == 1 || h->prof_stage == 3)) ++h->prof_n;
   return ITA_OK;
