@@ -48,7 +48,7 @@ STAGE_WORK = {   # stage: (ops per frame, bound, peak in Tera-op/s, arithmetic)
 
 # dominant-stage -> kernel whose PMC traffic (profiles/kernel_traffic.json, collected with
 # tools/profile_gpu.sh on this same command) is reported as roofline.traffic
-STAGE_KERNEL = {"encoder": "ita_stream_kernel<64, true, 1, false>", "tokenizer": "ita_tokenizer_kernel<64, false>",
+STAGE_KERNEL = {"encoder": "ita_stream_kernel<64, true, 1, false, false>", "tokenizer": "ita_tokenizer_kernel<64, false>",
                 "tail_decoder": "ita_gemm_f16x3_kernel<128, 128, 2, 4>", "lstm_fc": "ita_lstm_layer_kernel<4>"}
 # algorithmic HBM bytes per frame of each stage as it is cut here (inputs + outputs that cross a launch)
 STAGE_BYTES = {"tokenizer": 21600 + 128 * 64 * 4, "encoder": 128 * 64 * 4 + 2 * 128 * 64 * 2,
@@ -414,7 +414,7 @@ def main():
         achieved = ops * B / (max(dom_ms, 1e-9) * 1e-3) / 1e12
         kname = STAGE_KERNEL.get(dom, dom)
         if dom == "encoder":
-            kname = "ita_stream_kernel<64, true, 1, false>" if fused_tok else "ita_stream_kernel<64, true, 0, false>"
+            kname = "ita_stream_kernel<64, true, 1, false, false>" if fused_tok else "ita_stream_kernel<64, true, 0, false, false>"
         traffic, tsrc = pmc_traffic(kname, B)
         roof = {"kernel": kname, "stage": dom, "bound": bound, "achieved": round(achieved, 3),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 5), "traffic": traffic,
