@@ -105,7 +105,11 @@ int ita_ffn_int8_taps(ita_handle h, int layer, const float* x_dev, float* y_dev,
  * y = LN2(x1 + ffn(x1)),  x1 = LN1(x + mha(x)).  x_dev and y_dev may alias. */
 int ita_encoder_layer(ita_handle h, int layer, const float* x_dev, float* y_dev, int batch, void* stream);
 
-/* OverlapPatchMerging (models/ITA/QAT/layers.py:39-45): image (B,60,90) -> tokens (B,128,E). */
+/* OverlapPatchMerging (models/ITA/QAT/layers.py:39-45): image (B,60,90) -> tokens (B,128,E).
+ * ITA_IMAGE_F32: pixels already scaled to [0,1] (the reference host's float(pixel) / 255.0f, main.cpp:168-169).
+ * ITA_IMAGE_U8: the 8-bit wire codes as they arrive (main.cpp:37,166); the division by 255 is folded, with the 1/256 of
+ * the exact integer bilinear blend, into the conv weights -- the same linear map rounded once per weight, so the tokens
+ * of the two forms agree to ~1e-6, not bit for bit (oracle/ita_oracle.c: ita_oracle_tokenizer_u8 / ita_oracle_tokenizer). */
 int ita_tokenizer(ita_handle h, const void* image_dev, int image_dtype, float* tokens_dev, int batch, void* stream);
 
 /* Fusion tail (QAT/model.py:116-121): x (B,128,E) -> (B,9,16,32) flattened, row stride 4608. */
