@@ -251,6 +251,13 @@ def test_full_size_properties(torch_cuda, oracle):
     idx = torch.tensor([1023, 0, 511, 300, 7], device="cuda")
     vs, (hs, cs) = eng.forward(img[idx], dv[idx], qt[idx], (h[:, idx].contiguous(), c[:, idx].contiguous()))
     assert torch.equal(vs, v1[idx]) and torch.equal(hs, h1[:, idx]) and torch.equal(cs, c1[:, idx])
+    # ... nor on which of the three folded-GEMM kernels serves the batch: one M tile (<= 32 frames, one wave per tile and
+    # K slice), two to four M tiles per workgroup (33..128), several such workgroups with a ragged last one (129..256),
+    # the 128 x 128-tile kernel (> 256); LSTM frame tiles of 32 with a ragged tail everywhere
+    for n in (32, 33, 65, 100, 128, 129, 200, 256, 257, 300):
+        sub = torch.arange(1023, 1023 - n, -1, device="cuda")
+        vn, (hn, cn) = eng.forward(img[sub], dv[sub], qt[sub], (h[:, sub].contiguous(), c[:, sub].contiguous()))
+        assert torch.equal(vn, v1[sub]) and torch.equal(hn, h1[:, sub]) and torch.equal(cn, c1[:, sub]), n
     sel = [0, 255, 256, 777, 1023]
     ov, oh, oc = oracle.forward(blob, fr["img_u8"][sel], fr["desvel"][sel], fr["quat"][sel],
                                 h.cpu().numpy()[:, sel], c.cpu().numpy()[:, sel])
