@@ -24,6 +24,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
 """
 import argparse
 import glob
+import contextlib
 import json
 import os
 import sys
@@ -262,10 +263,13 @@ def main():
                     help="u8: the wire format of the reference host (ita_wire.h; float(pixel)/255.0f of main.cpp:168-169 "
                          "is done on the device, bit-identically, inside the fused tokenizer+encoder kernel); "
                          "f32: the graph's own input type (stand-alone tokenizer launch, 4x the frame bytes)")
-    ap.add_argument("--hip-graph", choices=["auto", "on", "off"], default="auto",
-                    help="8 time steps per HIP-graph replay on two streams, front(t+1) overlapping back(t) "
-                         "(host.PipelinedSteps); auto: when a GPU gets at most 256 frames per step -- the encoder then leaves "
-                         "CUs free for the small LSTM kernels and the step is launch-bound")
+    ap.add_argument("--schedule", choices=["auto", "stream", "pipelined", "graph"], default="auto",
+                    help="stream: one ita_vitlstm_forward per step on one stream.  pipelined: ita_vitlstm_pipelined, the "
+                         "library's own two-stream loop (front(t+1) next to back(t), two host threads), 8 steps per call.  "
+                         "graph: the same pipeline captured in a HIP graph (host.PipelinedSteps).  auto: graph when a GPU "
+                         "gets at most 256 frames per step (the encoder then leaves CUs free for the LSTM kernels), else stream")
+    ap.add_argument("--hip-graph", choices=["auto", "on", "off"], default=None,
+                    help="older spelling: on = --schedule graph, off = --schedule stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE config 2 / config 5 legs (configs.c2, configs.c5)")
@@ -317,27 +321,50 @@ def main():
     vels = [torch.empty((B, 3), device=dev) for _ in range(2)]
     gather = itadist.VelocityGather(B, world, dev, total=total if strong else None)
     NG = 8                                        # time steps per graph replay
-    use_graph = (a.hip_graph == "on" or (a.hip_graph == "auto" and B <= 256)) and a.image_dtype == "u8" and K % NG == 0
-    if a.hip_graph == "on" and not use_graph:
-        raise SystemExit(f"--hip-graph on needs u8 frames and --steps that is a multiple of {NG}")
+    sched = {"on": "graph", "off": "stream"}.get(a.hip_graph, a.schedule)
+    if sched == "auto":
+        # measured (tools/pipeline_probe.py, bench --schedule ...): the graph replay and the library's two-thread loop give
+        # the same step at 128-256 frames (43 / 50 us: what the GPU overlaps of front(t+1) and back(t)); below that the
+        # graph wins (the step is launch-bound and a replay has no launches)
+        sched = "stream" if (B > 256 or a.image_dtype != "u8" or K % NG) else "graph"
+    if sched == "pipelined" and K % 40 == 0:
+        NG = 40        # steps per ita_vitlstm_pipelined call: the helper thread is started once per call
+    if sched != "stream" and (a.image_dtype != "u8" or K % NG):
+        raise SystemExit(f"--schedule {sched} needs u8 frames and --steps that is a multiple of {NG}")
     graph = None
-    if use_graph:
+    if sched == "graph":
         # NG steps per replay on two streams, front(t+1) overlapping back(t): host.PipelinedSteps
         graph = eng.pipelined_steps(B, NG)
         graph.img.copy_(img.unsqueeze(0).expand(NG, -1, -1, -1))
         graph.desvel.copy_(dv.reshape(1, B).expand(NG, -1)); graph.quat.copy_(qt.unsqueeze(0).expand(NG, -1, -1))
-        gather = itadist.VelocityGather(NG * B, world, dev)    # one all-gather per replay: the NG steps' velocities
+    elif sched == "pipelined":
+        class LibPipeline:
+            """NG steps per ita_vitlstm_pipelined call; same calling convention as host.PipelinedSteps here"""
+            def __init__(self):
+                self.vel = torch.empty((NG, B, 3), device=dev)
+                self.h, self.c = state[0]
+                self.sf, self.sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+                self.args = ([img] * NG, [dv.reshape(B)] * NG, [qt] * NG, (self.h, self.c), [self.vel[i] for i in range(NG)])
+
+            def __call__(self):
+                eng.pipelined(*self.args, self.sf, self.sb)     # joins on its front stream: run under torch.cuda.stream(sf)
+        graph = LibPipeline()
+    if graph is not None:
+        gather = itadist.VelocityGather(NG * B, world, dev)    # one all-gather per NG steps: their velocities
     torch.cuda.synchronize()
 
     def step(i):
         """one time step over this GPU's B streams (+ the asynchronous velocity all-gather for N > 1)"""
         if graph is not None:
-            if i % NG == 0:       # a replay covers steps i .. i + NG - 1
-                if world > 1:
-                    gather.ready()
-                graph()
-                if world > 1:
-                    gather.start(graph.vel.reshape(NG * B, 3))
+            if i % NG == 0:       # a replay / call covers steps i .. i + NG - 1
+                # (the library pipeline's calls and their all-gathers stay on its front stream: no join with another
+                #  stream between calls, the next call's fronts queue up behind this call's last back)
+                with torch.cuda.stream(graph.sf) if sched == "pipelined" else contextlib.nullcontext():
+                    if world > 1:
+                        gather.ready()
+                    graph()
+                    if world > 1:
+                        gather.start(graph.vel.reshape(NG * B, 3))
             return
         src, dst = state[i & 1], state[(i + 1) & 1]
         vel = vels[i & 1]
@@ -377,8 +404,8 @@ def main():
     dom = max(per, key=per.get)
     dom_plugin_stage = {"encoder": "mha", "tail_decoder": "tail", "lstm_fc": "lstm_fc", "tokenizer": "tokenizer"}[dom]
     # Timed region: exactly K steps.  Eager schedule: HIP events around the dominant kernel only, on every 8th step (its
-    # launch duration for the roofline is measured here, live, on the compute stream).  Graph schedule: a graph cannot
-    # carry timing events, so the dominant kernel is timed the same way in an eager pass right after the timed region.
+    # launch duration for the roofline is measured here, live, on the compute stream).  Pipelined / graph schedules: no timing
+    # events inside, so the dominant kernel is timed the same way in an eager pass right after the timed region.
     live = graph is None and not os.environ.get("ITA_BENCH_NOPROF")
     if live:
         eng.profile_begin(min(K, 512), every_n=8, only_stage=dom_plugin_stage)
@@ -455,8 +482,10 @@ def main():
                                    ", LSTM state carried, velocity all-gather",
                        "frames_per_gpu": B, "global_batch": frames_per_step, "parallelism": f"dp{world}",
                        "image_dtype": a.image_dtype, "weights": "seed-0 synthetic QAT (tests/golden)",
-                       "schedule": (f"{NG} steps per HIP-graph replay on two streams: front(t+1) overlaps back(t)"
-                                    if graph is not None else "one stream")},
+                       "schedule": {"stream": "one stream",
+                                    "graph": f"{NG} steps per HIP-graph replay on two streams: front(t+1) overlaps back(t)",
+                                    "pipelined": f"{NG} steps per ita_vitlstm_pipelined call: the library's two-stream loop, "
+                                                 "front(t+1) overlaps back(t)"}[sched]},
             "roofline": roof, "stages": stages,
             "stages_note": "per-stage times from an untimed 20-step eager pass with events around every stage (each event "
                            "costs a ~5 us stream bubble, so they sum to more than ms_per_step)",

@@ -10,6 +10,8 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "../../include/ita_mi355x.h"
@@ -89,7 +91,7 @@ struct ita_context {
   // workspace
   int cap = 0;
   bool ws_reserved = false;     // ita_reserve was called: the workspace is pinned (see ensure_workspace)
-  int front_cap[2] = {0, 0};    // workspace capacity when ita_vitlstm_front filled partial buffer 0 / 1
+  int front_cap[ITA_PART_BUFFERS] = {};   // workspace capacity when ita_vitlstm_front filled partial buffer i
   float *bufA = nullptr, *bufB = nullptr, *cat0 = nullptr, *cat1 = nullptr, *cat2 = nullptr, *gates = nullptr,
         *feat = nullptr;
   // per-stage profiling (ita_profile_begin / _end)
@@ -97,6 +99,9 @@ struct ita_context {
   int prof_max = 0, prof_n = 0;
   int prof_every = 1, prof_stage = -1, prof_calls = 0;   // sample every n-th forward; -1 = all stages, else one stage
   std::vector<hipEvent_t> prof_ev;   // per recorded forward: 1 + 1 + 2*L + 3 events
+  std::vector<hipEvent_t> pipe_ev;   // ita_vitlstm_pipelined: front-done / back-done rings + fork/join
+  float* pipe_h = nullptr;           // ita_vitlstm_pipelined: second copy of (h, c), 2 x (3, pipe_cap, 128)
+  int pipe_cap = 0;
   // fusion tail on large token grids (ita_fusion_tail_load / _large, BASELINE config 5)
   _Float16 *tl_hi = nullptr, *tl_lo = nullptr;   // [chunks][9][nt*16][32]
   float* tl_bias = nullptr;
@@ -173,7 +178,7 @@ void free_workspace(ita_context* c) {
   if (c->part) (void)hipFree(c->part);
   c->part = nullptr;
   c->cap = 0;
-  c->front_cap[0] = c->front_cap[1] = 0;
+  for (int& fc : c->front_cap) fc = 0;
 }
 
 // Growth frees and reallocates every buffer, so it is only allowed while nothing can still reference the old ones:
@@ -201,7 +206,7 @@ int ensure_workspace(ita_context* c, int B, hipStream_t s = nullptr) {
   HIPCHK(hipMalloc(&c->c1_lo, 2 * (size_t)((B + 31) / 32 * 32) * 256));   // fragment order, whole 32-frame tiles
   HIPCHK(hipMalloc(&c->c2_hi, 2 * (size_t)((B + 31) / 32 * 32) * 256));   // fragment order, whole 32-frame tiles
   HIPCHK(hipMalloc(&c->c2_lo, 2 * (size_t)((B + 31) / 32 * 32) * 256));   // fragment order, whole 32-frame tiles
-  HIPCHK(hipMalloc(&c->part, 2 * sizeof(float) * (size_t)NSPLIT * B * 512));   // two buffers: ita_vitlstm_front/back
+  HIPCHK(hipMalloc(&c->part, ITA_PART_BUFFERS * sizeof(float) * (size_t)NSPLIT * B * 512));   // ita_vitlstm_front/back
   c->cap = B;
   return ITA_OK;
 }
@@ -753,6 +758,8 @@ int ita_destroy(ita_handle h) {
   free_weights(h);
   free_workspace(h);
   for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->pipe_ev) (void)hipEventDestroy(e);
+  if (h->pipe_h) (void)hipFree(h->pipe_h);
   if (h->dsp_in) (void)hipFree(h->dsp_in);
   if (h->dsp_out) (void)hipFree(h->dsp_out);
   free_tail_large(h);
@@ -1240,7 +1247,7 @@ static int front_impl(ita_handle h, const void* image, int image_dtype, int batc
                       void* encoder_done_event) {
   int rc = check(h, batch);
   if (rc) return rc;
-  if (!image || (buf != 0 && buf != 1)) return fail(ITA_ERR_INVALID_ARG, "null image or buf not in {0,1}");
+  if (!image || buf < 0 || buf >= ITA_PART_BUFFERS) return fail(ITA_ERR_INVALID_ARG, "null image or buf not in [0, ITA_PART_BUFFERS)");
   if (image_dtype != ITA_IMAGE_F32 && image_dtype != ITA_IMAGE_U8) return fail(ITA_ERR_INVALID_ARG, "bad image dtype");
   if (!(h->tail_mode == 1 && h->folded)) return fail(ITA_ERR_UNSUPPORTED, "front/back form needs tail mode 1 and a full ITAViTLSTM blob");
   if ((rc = ensure_workspace(h, batch, (hipStream_t)stream))) return rc;
@@ -1291,8 +1298,8 @@ int ita_vitlstm_back(ita_handle h, const float* desvel, const float* quat, const
                      float* h_out, float* c_out, int batch, int buf, void* stream) {
   int rc = check(h, batch);
   if (rc) return rc;
-  if (!desvel || !quat || !h_in || !c_in || !vel || !h_out || !c_out || (buf != 0 && buf != 1))
-    return fail(ITA_ERR_INVALID_ARG, "null pointer or buf not in {0,1}");
+  if (!desvel || !quat || !h_in || !c_in || !vel || !h_out || !c_out || buf < 0 || buf >= ITA_PART_BUFFERS)
+    return fail(ITA_ERR_INVALID_ARG, "null pointer or buf not in [0, ITA_PART_BUFFERS)");
   if (!(h->tail_mode == 1 && h->folded)) return fail(ITA_ERR_UNSUPPORTED, "front/back form needs tail mode 1 and a full ITAViTLSTM blob");
   if (batch > h->cap || h->front_cap[buf] != h->cap)
     return fail(ITA_ERR_INVALID_ARG, "ita_vitlstm_front has not filled this buffer for the current workspace (reserve before front)");
@@ -1322,6 +1329,81 @@ int ita_vitlstm_back(ita_handle h, const float* desvel, const float* quat, const
   hipLaunchKernelGGL(ita_fc_kernel, dim3((B * 3 + 63) / 64), dim3(64), 0, s, h_out + 2 * lstride, h->fc_w, h->fc_b, vel, B,
                      (const int*)nullptr);
   HIPCHK(hipGetLastError());
+  return ITA_OK;
+}
+
+// n consecutive time steps, software-pipelined from the host: front(t+1) on stream_front while back(t) is on stream_back
+int ita_vitlstm_pipelined(ita_handle h, const void* const* image, int image_dtype, const float* const* desvel,
+                          const float* const* quat, float* state_h, float* state_c, float* const* vel, int batch, int n_steps,
+                          void* stream_front, void* stream_back) {
+  int rc = check(h, batch);
+  if (rc) return rc;
+  if (!image || !desvel || !quat || !state_h || !state_c || !vel || n_steps <= 0 || !stream_front || !stream_back ||
+      stream_front == stream_back)
+    return fail(ITA_ERR_INVALID_ARG, "null argument, n_steps <= 0, or the two streams are not two distinct non-default streams");
+  if ((rc = ensure_workspace(h, batch, (hipStream_t)stream_front))) return rc;
+  hipStream_t sf = (hipStream_t)stream_front, sb = (hipStream_t)stream_back;
+  const size_t nstate = (size_t)3 * batch * 128;
+  if (h->pipe_cap < batch) {   // the second copy of the state, so that no step updates its state in place
+    if (h->pipe_h) (void)hipFree(h->pipe_h);
+    h->pipe_h = nullptr; h->pipe_cap = 0;
+    HIPCHK(hipMalloc(&h->pipe_h, 2 * nstate * sizeof(float)));
+    h->pipe_cap = batch;
+  }
+  while ((int)h->pipe_ev.size() < 2 * ITA_PART_BUFFERS + 1) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    h->pipe_ev.push_back(e);
+  }
+  hipEvent_t* evf = h->pipe_ev.data();                       // front(t) done, ring of ITA_PART_BUFFERS
+  hipEvent_t* evb = h->pipe_ev.data() + ITA_PART_BUFFERS;    // back(t) done
+  float* sh[2] = {state_h, h->pipe_h};
+  float* sc[2] = {state_c, h->pipe_h + nstate};
+  // the back stream starts after what the caller has already put on the front stream (the state it hands over)
+  HIPCHK(hipEventRecord(h->pipe_ev[2 * ITA_PART_BUFFERS], sf));
+  HIPCHK(hipStreamWaitEvent(sb, h->pipe_ev[2 * ITA_PART_BUFFERS], 0));
+  // Two host threads, one per stream: a step is about six kernel launches and three event calls, 31-37 us of host time
+  // when one thread issues them all -- about what the GPU needs for a 128-frame step.  The calling thread issues
+  // the fronts, a helper the backs; they hand over "event t has been recorded / waited for" through two counters,
+  // because hipStreamWaitEvent must come after the hipEventRecord it refers to in HOST order.
+  std::atomic<int> fronts_recorded{0}, backs_recorded{0}, abort_flag{0};
+  int rc_back = ITA_OK;
+  std::thread back_thread([&]() {
+    for (int t = 0; t < n_steps; ++t) {
+      const int buf = t % ITA_PART_BUFFERS;
+      while (fronts_recorded.load(std::memory_order_acquire) <= t)
+        if (abort_flag.load(std::memory_order_relaxed)) return;
+      if (hipStreamWaitEvent(sb, evf[buf], 0) != hipSuccess) { rc_back = fail(ITA_ERR_HIP, "hipStreamWaitEvent (back stream)"); break; }
+      if ((rc_back = ita_vitlstm_back(h, desvel[t], quat[t], sh[t & 1], sc[t & 1], vel[t], sh[(t + 1) & 1], sc[(t + 1) & 1], batch,
+                                      buf, sb)))
+        break;
+      if (hipEventRecord(evb[buf], sb) != hipSuccess) { rc_back = fail(ITA_ERR_HIP, "hipEventRecord (back stream)"); break; }
+      backs_recorded.store(t + 1, std::memory_order_release);
+    }
+    if (rc_back) abort_flag.store(1, std::memory_order_relaxed);
+  });
+  for (int t = 0; t < n_steps && !rc; ++t) {
+    const int buf = t % ITA_PART_BUFFERS;
+    if (t >= ITA_PART_BUFFERS) {   // front(t) overwrites what back(t - NB) read
+      while (backs_recorded.load(std::memory_order_acquire) <= t - ITA_PART_BUFFERS && !abort_flag.load(std::memory_order_relaxed)) {}
+      if (abort_flag.load(std::memory_order_relaxed)) break;
+      if (hipStreamWaitEvent(sf, evb[buf], 0) != hipSuccess) { rc = fail(ITA_ERR_HIP, "hipStreamWaitEvent (front stream)"); break; }
+    }
+    if ((rc = ita_vitlstm_front(h, image[t], image_dtype, batch, buf, sf))) break;
+    if (hipEventRecord(evf[buf], sf) != hipSuccess) { rc = fail(ITA_ERR_HIP, "hipEventRecord (front stream)"); break; }
+    fronts_recorded.store(t + 1, std::memory_order_release);
+  }
+  if (rc) abort_flag.store(1, std::memory_order_relaxed);
+  back_thread.join();
+  if (rc) return rc;
+  if (rc_back) return fail(rc_back, "ita_vitlstm_pipelined: the back stream's host thread failed (see the earlier error)");
+  if (n_steps & 1) {   // an odd number of steps leaves the state in the internal copy
+    HIPCHK(hipMemcpyAsync(state_h, sh[1], nstate * sizeof(float), hipMemcpyDeviceToDevice, sb));
+    HIPCHK(hipMemcpyAsync(state_c, sc[1], nstate * sizeof(float), hipMemcpyDeviceToDevice, sb));
+  }
+  // join: everything is complete in stream_front's order
+  HIPCHK(hipEventRecord(h->pipe_ev[2 * ITA_PART_BUFFERS], sb));
+  HIPCHK(hipStreamWaitEvent(sf, h->pipe_ev[2 * ITA_PART_BUFFERS], 0));
   return ITA_OK;
 }
 

@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = (
     "ita_profile_begin", "ita_profile_begin_sampled", "ita_profile_end", "ita_set_tail_mode", "ita_debug_encoder_stamps",
     "ita_fusion_tail_load", "ita_fusion_tail_large",
     "ita_wire_unpack_packet", "ita_wire_postprocess", "ita_vitlstm_forward_slots", "ita_vitlstm_front",
-    "ita_vitlstm_back", "ita_vitlstm_front_ev", "ita_vitlstm_tail", "ita_debug_softmax_rows",
+    "ita_vitlstm_back", "ita_vitlstm_pipelined", "ita_vitlstm_front_ev", "ita_vitlstm_tail", "ita_debug_softmax_rows",
     "ITASelfAttention_workgroup", "ITASelfAttention_workgroup_expanded", "ITAFeedForward_workgroup",
 )
 
@@ -116,6 +116,7 @@ def lib():
         L.ita_vitlstm_front.argtypes = [vp, vp, i, i, i, vp]
         L.ita_vitlstm_front_ev.argtypes = [vp, vp, i, i, i, vp, vp]
         L.ita_vitlstm_back.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp]
+        L.ita_vitlstm_pipelined.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, i, i, vp, vp]
         L.ita_mha_q8.argtypes = [vp, i, vp, vp, i, vp]
         L.ita_vitlstm_tail.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, vp]
         L.ita_debug_softmax_rows.argtypes = [vp, vp, vp, i, vp]
@@ -387,6 +388,16 @@ class Engine:
         _chk(lib().ita_vitlstm_front_ev(self._h, img.data_ptr(), dt, img.shape[0], buf, sp, ev))
         return img.shape[0]
 
+    def pipelined(self, imgs, desvels, quats, state, vels, stream_front, stream_back):
+        """n time steps pipelined on two torch streams by the library (ita_vitlstm_pipelined): imgs / desvels / quats /
+        vels are sequences of per-step tensors (or a tensor with a leading step axis), state = (h, c) updated in place"""
+        n = len(imgs)
+        B = imgs[0].shape[0]
+        dt = 1 if imgs[0].dtype == _torch().uint8 else 0
+        arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        _chk(lib().ita_vitlstm_pipelined(self._h, arr(imgs), dt, arr(desvels), arr(quats), state[0].data_ptr(), state[1].data_ptr(),
+                                         arr(vels), B, n, C.c_void_p(stream_front.cuda_stream), C.c_void_p(stream_back.cuda_stream)))
+
     def back(self, desvel, quat, hidden, out, buf: int, stream=None):
         """state half of a time step (LSTM + fc) from buffer `buf`; out = (vel, h_out, c_out) tensors"""
         B = out[0].shape[0]
@@ -463,11 +474,15 @@ class GraphedStep:
         return self.vel
 
 
+PART_BUFFERS = 8    # ITA_PART_BUFFERS of include/ita_mi355x.h: partial-sum buffers of the front/back form
+
+
 class PipelinedSteps:
     """`n_steps` consecutive time steps captured in ONE HIP graph on two streams: the image-only front of step t+1
     (tokenizer, encoder, folded GEMM: ita_vitlstm_front) runs while the recurrent back of step t (LSTM layers, fc:
     ita_vitlstm_back) is still in flight.  The recurrence is respected -- back(t) follows back(t-1) on its stream and
-    front(t) -- and so is the reuse of the two partial-sum buffers (front(t) waits for back(t-2)).  This pays when a GPU
+    front(t) -- and so is the reuse of the partial-sum buffers (front(t) waits for back(t - PART_BUFFERS); with n_steps <=
+    PART_BUFFERS the front stream never waits for the back stream inside a replay).  This pays when a GPU
     holds few streams (up to ~256: the strong-scaling regime of BASELINE config 4 on 8 GPUs): the encoder then leaves CUs
     free for the small LSTM kernels, and one graph launch replaces 6 * n_steps kernel launches.  At 1024 streams per GPU
     the encoder owns every CU and nothing overlaps (measured), so bench.py uses this below 256 streams only.
@@ -500,14 +515,18 @@ class PipelinedSteps:
         s_front, s_back = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
         ev_front = [torch.cuda.Event() for _ in range(n_steps)]
         ev_back = [torch.cuda.Event() for _ in range(n_steps)]
+        # Two partial buffers, although the library has PART_BUFFERS: with front(i) waiting for back(i-2) the HIP runtime
+        # overlaps the two branches of the replayed graph (41.9 us per 128-frame step for 32.6 us of front and 17.3 us of
+        # back); without that edge (8 buffers) it runs them one after the other (52.5 us; tools/pipeline_probe.py).
+        nb = 2
         with torch.cuda.graph(self.graph, stream=s_front):
             for i in range(n_steps):
-                if i >= 2:
-                    s_front.wait_event(ev_back[i - 2])          # front(i) overwrites the partial buffer back(i-2) read
-                engine.front(self.img[i], i & 1, stream=s_front)
+                if i >= nb:
+                    s_front.wait_event(ev_back[i - nb])         # front(i) overwrites the partial buffer back(i-nb) read
+                engine.front(self.img[i], i % nb, stream=s_front)
                 ev_front[i].record(s_front)
                 s_back.wait_event(ev_front[i])                  # (also forks s_back into the capture at i = 0)
-                engine.back(self.desvel[i], self.quat[i], (self.h, self.c), (self.vel[i], self.h, self.c), i & 1, stream=s_back)
+                engine.back(self.desvel[i], self.quat[i], (self.h, self.c), (self.vel[i], self.h, self.c), i % nb, stream=s_back)
                 ev_back[i].record(s_back)
             s_front.wait_stream(s_back)                          # join
         self.h.zero_()

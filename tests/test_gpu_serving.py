@@ -187,6 +187,35 @@ def test_pipelined_graph_steps_equal_sequential_forward(B):
     eng.close(); eng2.close()
 
 
+@pytest.mark.parametrize("B,n", [(3, 5), (130, 12)])
+def test_library_pipelined_steps_equal_sequential_forward(B, n):
+    """ita_vitlstm_pipelined (the library's own two-stream loop: front(t+1) next to back(t), ping-pong state, event
+    ordering, an odd step count leaving the state in the internal copy, more steps than partial buffers) must give exactly
+    the velocities and the final state of n sequential ita_vitlstm_forward calls."""
+    import torch
+    fx = params.load_fixture(os.path.join(os.path.dirname(__file__), "golden", "vitlstm_E64_seed0_B2.npz"))
+    eng = host.Engine(params.blob_from_record(fx, synth.float_params(0, E=64), E=64), device=0)
+    frs = [synth.frames(700 + t, B) for t in range(n)]
+    imgs = [torch.from_numpy(f["img_u8"]).cuda() for f in frs]
+    dvs = [torch.from_numpy(f["desvel"]).reshape(B).cuda() for f in frs]
+    qts = [torch.from_numpy(f["quat"]).cuda() for f in frs]
+    rs = np.random.RandomState(9)
+    h0 = torch.from_numpy(rs.standard_normal((3, B, 128)).astype(np.float32) * 0.1).cuda()
+    c0 = torch.from_numpy(rs.standard_normal((3, B, 128)).astype(np.float32) * 0.1).cuda()
+    h, c = h0.clone(), c0.clone()
+    vels = [torch.empty((B, 3), dtype=torch.float32, device="cuda") for _ in range(n)]
+    sf, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    eng.pipelined(imgs, dvs, qts, (h, c), vels, sf, sb)
+    sf.synchronize()                      # the call joins on the front stream
+    st = (h0, c0)
+    for t in range(n):
+        v, st = eng.forward(imgs[t], dvs[t], qts[t], st)
+        assert torch.equal(vels[t], v), f"step {t}"
+    assert torch.equal(h, st[0]) and torch.equal(c, st[1])
+    eng.close()
+
+
 def test_udp_server_evicts_least_recent_stream(oracle):
     """--max-streams 2 with three senders: the third sender takes the slot of the sender that has been silent longest and
     starts from ZERO state (round 1 dropped every sender beyond the table size forever); a returning evicted sender
