@@ -180,26 +180,14 @@ __global__ __launch_bounds__(64 * WM * WN) void ita_gemm_f16x3_kernel(const ItaG
 // frame's result does not depend on which of the two kernels served its batch (tests: a 5-frame batch against
 // rows of a 1024-frame batch, bit for bit).
 // k-tiles in the LDS ring (4..8 where 160 KB hold them measured 1-3 % slower at every M)
-constexpr int ita_gemm_small_nstg(int mt) { return 3; }
-constexpr int ita_gemm_small_lds(int mt) { return ita_gemm_small_nstg(mt) * (2 * mt + 2) * 32 * 128; }
+constexpr int ITA_GEMM_SMALL_NSTG = 3;
+constexpr int ita_gemm_small_lds(int mt) { return ITA_GEMM_SMALL_NSTG * (2 * mt + 2) * 32 * 128; }
 constexpr int ita_waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }   // s_waitcnt vmcnt(n) only
-template <int DMA>
-__device__ __forceinline__ void wait_dma_tiles(int younger) {   // until at most `younger` k-tiles of this wave's DMA are outstanding
-  switch (younger) {
-    case 0: __builtin_amdgcn_s_waitcnt(ita_waitcnt_vm(0)); break;
-    case 1: __builtin_amdgcn_s_waitcnt(ita_waitcnt_vm(DMA)); break;
-    case 2: __builtin_amdgcn_s_waitcnt(ita_waitcnt_vm(2 * DMA)); break;
-    case 3: __builtin_amdgcn_s_waitcnt(ita_waitcnt_vm(3 * DMA < 63 ? 3 * DMA : 63)); break;
-    case 4: __builtin_amdgcn_s_waitcnt(ita_waitcnt_vm(4 * DMA < 63 ? 4 * DMA : 63)); break;
-    case 5: __builtin_amdgcn_s_waitcnt(ita_waitcnt_vm(5 * DMA < 63 ? 5 * DMA : 63)); break;
-    default: __builtin_amdgcn_s_waitcnt(ita_waitcnt_vm(6 * DMA < 63 ? 6 * DMA : 63)); break;
-  }
-}
 template <int MT>
 __global__ __launch_bounds__(256) void ita_gemm_f16x3_small_kernel(const ItaGemmSplitArgs g) {
-  constexpr int NSTG = ita_gemm_small_nstg(MT), PLANE = 32 * 128, APL = MT * PLANE, STG = 2 * APL + 2 * PLANE;
+  constexpr int NSTG = ITA_GEMM_SMALL_NSTG, PLANE = 32 * 128, APL = MT * PLANE, STG = 2 * APL + 2 * PLANE;
   constexpr int DMA = 2 * MT + 2;   // LDS-DMA wave-instructions per wave and k-tile
-  static_assert(DMA * (NSTG - 1) < 64 && NSTG <= 8, "vmcnt range");
+  static_assert(NSTG == 3 && DMA < 64, "one younger k-tile in flight at the wait; vmcnt range");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
   const int z = blockIdx.x % g.nsplit, n0 = (blockIdx.x / g.nsplit) * 32, m0 = blockIdx.y * 128;
@@ -223,7 +211,7 @@ __global__ __launch_bounds__(256) void ita_gemm_f16x3_small_kernel(const ItaGemm
     // The compiler does not track LDS-DMA, so the waits are explicit.  This wave's pieces of tile kt have landed when
     // at most those of the younger tiles are outstanding; the barrier then says the same of every wave's pieces
     // -- and that every wave has finished reading tile kt - 1, whose slot the next stage call refills.
-    wait_dma_tiles<DMA>(min(nt - 1 - kt, NSTG - 2));
+    if (kt + 1 < nt) __builtin_amdgcn_s_waitcnt(ita_waitcnt_vm(DMA)); else __builtin_amdgcn_s_waitcnt(ita_waitcnt_vm(0));
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's fragment reads of tile kt - 1 have returned
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
