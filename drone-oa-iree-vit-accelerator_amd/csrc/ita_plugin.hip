@@ -301,7 +301,7 @@ template <int E, bool FFN, bool TOK>
 int build_stream_image(const StreamHostParams& p, char** d_out) {
   using L = ItaStreamLds<E, FFN, TOK>;
   constexpr int P = 192, F = 256;
-  std::vector<char> im(L::IMAGE, 0);
+  std::vector<char> im(L::GIMAGE, 0);   // (E = 128 with FFN: fc1 / fc2 weights lie behind the LDS part)
   auto natural = [&](int off, const int8_t* w, int rows, int kb) {
     for (int r = 0; r < rows; ++r)
       for (int k = 0; k < kb; ++k) im[off + (((k >> 4) * rows + r) << 4) + (k & 15)] = (char)w[(size_t)r * kb + k];
@@ -329,8 +329,8 @@ int build_stream_image(const StreamHostParams& p, char** d_out) {
     for (int i = 0; i < L::NBIAS; ++i) bias[i] = (int32_t)((uint32_t)bias[i] + (uint32_t)ITA_ACC_BIAS);
   };
   if constexpr (FFN) {
-    natural(L::W1, p.w1, F, E);
-    fragment(L::W2, p.w2, 4, F);
+    natural(L::W12G ? L::GW1 : L::W1, p.w1, F, E);
+    fragment(L::W12G ? L::GW2 : L::W2, p.w2, 4, F);
     memcpy(bias + 3 * P + E, p.b1, F * 4); memcpy(bias + 3 * P + E + F, p.b2, E * 4);
     memcpy(ln + 2 * E, p.n2w, E * 4); memcpy(ln + 3 * E, p.n2b, E * 4);
   }
@@ -423,7 +423,10 @@ int launch_stream(ita_context* c, int layer, int mode, bool fuse_ln, const Strea
   } else {
     if (!L.simg_enc) return fail(ITA_ERR_BAD_BLOB, "LayerNorm parameters missing from the blob");
     a.image = L.simg_enc;
-    if (io.stamps) hipLaunchKernelGGL((ita_stream_kernel<64, true, 0, true>), dim3(grid), dim3(512), (ItaStreamLds<64, true, false>::TOTAL), s, a);
+    if (c->hdr.E == 128) {   // attention + FFN of an E = 128 layer in one launch; fc1 / fc2 weights are read from the global image
+      if (io.stamps) return fail(ITA_ERR_UNSUPPORTED, "phase stamps are built for the E = 64 encoder");
+      hipLaunchKernelGGL((ita_stream_kernel<128, true, 0>), dim3(grid), dim3(512), (ItaStreamLds<128, true, false>::TOTAL), s, a);
+    } else if (io.stamps) hipLaunchKernelGGL((ita_stream_kernel<64, true, 0, true>), dim3(grid), dim3(512), (ItaStreamLds<64, true, false>::TOTAL), s, a);
     else hipLaunchKernelGGL((ita_stream_kernel<64, true, 0>), dim3(grid), dim3(512), (ItaStreamLds<64, true, false>::TOTAL), s, a);
   }
   HIPCHK(hipGetLastError());
@@ -731,6 +734,7 @@ int ita_create(ita_handle* out, int device_ordinal) {
   if ((rc = set_lds(ita_stream_kernel<64, true, 0, true>, ItaStreamLds<64, true, false>::TOTAL))) { delete c; return rc; }
   if ((rc = set_lds(ita_stream_kernel<64, false, 0>, ItaStreamLds<64, false, false>::TOTAL))) { delete c; return rc; }
   if ((rc = set_lds(ita_stream_kernel<128, false, 0>, ItaStreamLds<128, false, false>::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_stream_kernel<128, true, 0>, ItaStreamLds<128, true, false>::TOTAL))) { delete c; return rc; }
   if ((rc = set_lds(ita_stream_kernel<64, false, 0, false, true>, ItaStreamLds<64, false, false>::TOTAL))) { delete c; return rc; }
   if ((rc = set_lds(ita_stream_kernel<128, false, 0, false, true>, ItaStreamLds<128, false, false>::TOTAL))) { delete c; return rc; }
   {
@@ -854,6 +858,7 @@ int ita_load_weights(ita_handle h, const void* blob, size_t nbytes) {
       if (!rc2 && lns && i == 0 && sp.tlw && sp.tlb && sp.conv_w && sp.conv_b) rc2 = build_stream_image<64, true, true>(sp, &L.simg_tok);
     } else {
       rc2 = build_stream_image<128, false, false>(sp, &L.simg_mha);
+      if (!rc2 && lns) rc2 = build_stream_image<128, true, false>(sp, &L.simg_enc);
     }
     if (rc2) { free_weights(h); return rc2; }
   }

@@ -75,9 +75,12 @@ struct ItaStreamLds {
   static constexpr int WK = WQ + P * E;
   static constexpr int WV = WK + P * E;
   static constexpr int WO = WV + P * E;              // int8 [12][E][16]     fragment order (see build_stream_image)
+  // E = 128: attention weights (98 KB) + K / V^T (49 KB) fill the LDS, so fc1 / fc2 (64 KB) stay in GLOBAL memory (the image
+  // continues behind the part that is copied to LDS) and are read as fragments, L2-resident, once per frame
+  static constexpr bool W12G = FFN && E > 64;
   static constexpr int W1 = WO + E * P;              // int8 [E/16][256][16] natural k
-  static constexpr int W2 = W1 + (FFN ? F * E : 0);  // int8 [16][E][16]     fragment order
-  static constexpr int BIAS = W2 + (FFN ? E * F : 0);   // int32: bq | bk | bv | bo | b1 | b2
+  static constexpr int W2 = W1 + ((FFN && !W12G) ? F * E : 0);  // int8 [16][E][16]     fragment order
+  static constexpr int BIAS = W2 + ((FFN && !W12G) ? E * F : 0);   // int32: bq | bk | bv | bo | b1 | b2
   static constexpr int NBIAS = 3 * P + E + (FFN ? F + E : 0);
   static constexpr int LNP = BIAS + NBIAS * 4;       // f32: n1w | n1b | n2w | n2b | tok_lnw | tok_lnb
   static constexpr int NLN = 2 * E + (FFN ? 2 * E : 0) + (TOK ? 2 * E : 0);
@@ -86,6 +89,8 @@ struct ItaStreamLds {
   static constexpr int TAP = CB + (TOK ? E * 4 : 0);            // int32 [52]: window offset ky * 96 + kx of tap t (0 for t >= 49)
   static constexpr int VB4 = TAP + (TOK ? 52 * 4 : 0);          // int32 [192][4]: bv replicated (V accumulators start per COLUMN)
   static constexpr int IMAGE = VB4 + P * 16;
+  static constexpr int GW1 = IMAGE, GW2 = GW1 + F * E;               // W12G: offsets in the global image
+  static constexpr int GIMAGE = W12G ? GW2 + E * F : IMAGE;          // bytes of the device image
   // ---- built / used at run time
   static constexpr int K = IMAGE;                    // int8 [12][128][16]  fragment order
   static constexpr int VT = K + S * P;               // int8 [8][192][16]   V^T, keys permuted (ita_int8_kernels.h)
@@ -691,6 +696,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if constexpr (TOK != 0 && !(ITA_ABLATE & 4)) { if (more) tok_blend(ol); }
 
     // ---------------- out_proj + residual + LayerNorm1 (k-step 0 of the first group is already in flight)
+    const char* w1p = lds + L::W1;   // fc1 / fc2 weights: LDS image, or (E = 128) the global image behind it
+    const char* w2p = lds + L::W2;
+    if constexpr (L::W12G) { w1p = a.image + L::GW1; w2p = a.image + L::GW2; }
     float x1[EC];
     ItaFr<4 * NK> ffr[2];
     i32x4 fa[3][4];
@@ -702,7 +710,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int cur = (3 * eg + ks) & 1;
         if (ks + 1 < 3) ld_frg_ks<E>(ob[cur ^ 1], lds + L::WO, 4 * eg, ks + 1, qi, kq);
         else if (eg + 1 < EG) ld_frg_ks<E>(ob[cur ^ 1], lds + L::WO, 4 * (eg + 1), 0, qi, kq);
-        else if constexpr (FFN) ld_nat<NK, F>(ffr[0], fa[0], lds + L::W1, l_b1, 0, qi, kq);
+        else if constexpr (FFN) ld_nat<NK, F>(ffr[0], fa[0], w1p, l_b1, 0, qi, kq);
         mm_ks(ob[cur], cf[ks], oa);
         ITA_SCHED_BARRIER();   // keep the step's loads ahead of the next step's MFMAs
       }
@@ -736,7 +744,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if constexpr (FFN) {
       // ---------------- FFN: fc1 + ReLU (hidden layer = four B fragments in registers) -> fc2 -> LayerNorm2.
       // fc2's k-step ks consumes hidden fragment ks: its MFMAs are issued one step behind fc1's epilogue.
-      static_assert(!FFN || EG == 1, "the fused FFN is written for E = 64");
       i32x4 x1f[NK];
 #pragma unroll
       for (int c = 0; c < NK; ++c) {
@@ -749,24 +756,42 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       ld_obias<E>(ya, l_b2, 0, kq);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        if (g + 1 < 4) ld_nat<NK, F>(ffr[(g + 1) & 1], fa[(g + 1) % 3], lds + L::W1, l_b1, 4 * (g + 1), qi, kq);
-        if (g >= 1) ld_frg_ks<E>(wb[(g - 1) & 1], lds + L::W2, 0, g - 1, qi, kq);
+        if (g + 1 < 4) ld_nat<NK, F>(ffr[(g + 1) & 1], fa[(g + 1) % 3], w1p, l_b1, 4 * (g + 1), qi, kq);
+        if (g >= 1) ld_frg_ks<E>(wb[(g - 1) & 1], w2p, 0, g - 1, qi, kq);
         mm_group<NK, false>(ffr[g & 1], x1f, fa[g % 3]);
         if (g >= 2) mm_ks(wb[(g - 2) & 1], hf[g - 2], ya);
         if constexpr (TOK != 0 && ITA_TOK_MID && !(ITA_ABLATE & 4)) { if (more) { tok_step(4 + 2 * g, ol); tok_step(5 + 2 * g, ol); } }
         if (g >= 1) hf[g - 1] = rq_group(fa[(g - 1) % 3], a.m1, 0.0f);
         ITA_SCHED_BARRIER();   // keep the step's loads ahead of the next step's MFMAs
       }
-      ld_frg_ks<E>(wb[1], lds + L::W2, 0, 3, qi, kq);
+      ld_frg_ks<E>(wb[1], w2p, 0, 3, qi, kq);
       mm_ks(wb[0], hf[2], ya);
       hf[3] = rq_group(fa[3 % 3], a.m1, 0.0f);
       mm_ks(wb[1], hf[3], ya);
       if constexpr (TOK != 0 && ITA_TOK_MID && !(ITA_ABLATE & 4)) { if (more) tok_step(12, ol); }
       ITA_SSTAMP(8);
-      float d[16];
-      dq_group(ya, a.m2, a.s2, d);
+      {
+        float d[16];
+        dq_group(ya, a.m2, a.s2, d);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) yv[j] = x1[j] + d[j];
+        for (int j = 0; j < 16; ++j) yv[j] = x1[j] + d[j];
+      }
+      // E = 128: the second half of the output channels, from the same hidden fragments
+#pragma unroll
+      for (int eg = 1; eg < EG; ++eg) {
+        ld_obias<E>(ya, l_b2, 4 * eg, kq);
+        ld_frg_ks<E>(wb[0], w2p, 4 * eg, 0, qi, kq);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          if (ks + 1 < 4) ld_frg_ks<E>(wb[(ks + 1) & 1], w2p, 4 * eg, ks + 1, qi, kq);
+          mm_ks(wb[ks & 1], hf[ks], ya);
+          ITA_SCHED_BARRIER();
+        }
+        float d[16];
+        dq_group(ya, a.m2, a.s2, d);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) yv[16 * eg + j] = x1[16 * eg + j] + d[j];
+      }
       layernorm_q16<E>(yv, lnp + 2 * E, lnp + 3 * E, EC * kq);
     } else {
 #pragma unroll
