@@ -843,3 +843,109 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     a.stamps[(((size_t)blockIdx.x * 8) * 2 + (wave >> 2)) * 16 + 14] = __builtin_amdgcn_s_memrealtime();
 #undef ITA_SSTAMP
 }
+
+// ------------------------------------------------------------------ the tokenizer of u8 wire frames on its own
+// OverlapPatchMerging (reference models/ITA/QAT/layers.py:39-45) with the arithmetic of the fused tokenizer above -- per-wave
+// 9-row pixel windows, the exact integer blend of the pixel codes as the lane's own MFMA B operand, conv weights
+// x 1/65280 as v_mfma_f32_16x16x4_f32 A fragments, LayerNorm in registers -- for the cases the fused form does not cover:
+// E = 128 (its encoder kernel has no LDS left for the 27 KB of conv fragments) and callers of ita_tokenizer.  Wave w = token
+// row w of the 8 x 16 grid; one persistent 512-thread workgroup per CU, the next frame's pixels requested a frame ahead.
+// Same results as ita_tokenizer_kernel<E, true> bit for bit (same operation order), at a quarter of its time.
+template <int E>
+struct ItaTokStreamLds {
+  static constexpr int NCT = E / 16;                           // 16-channel output tiles
+  static constexpr int LNP = 0;                                // f32: ln_w | ln_b
+  static constexpr int CW = LNP + 2 * E * 4;                   // f32 [13][NCT][64]: conv weights x 1/65280 as A fragments
+  static constexpr int CB = CW + 13 * NCT * 64 * 4;            // f32 [E]
+  static constexpr int TAP = CB + E * 4;                       // int32 [52]
+  static constexpr int IMAGE = TAP + 52 * 4;
+  static constexpr int IMG = (IMAGE + 15) & ~15;               // u8 [8 waves][9][96]
+  static constexpr int IMG_WAVE = 9 * 96;
+  static constexpr int TOTAL = IMG + 8 * IMG_WAVE;
+};
+struct ItaTokStreamArgs {
+  const char* image;     // device copy of the LDS image (ItaTokStreamLds<E>::IMAGE bytes)
+  const void* img;       // (B,60,90) u8
+  float* tokens;         // (B,128,E)
+  int B;
+};
+template <int E>
+__global__ __launch_bounds__(512) void ita_tok_stream_kernel(const ItaTokStreamArgs a) {
+  using L = ItaTokStreamLds<E>;
+  constexpr int S = 128, EC = E / 4, NCT = L::NCT;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float* lnp = (const float*)(lds + L::LNP);
+  // geometry of this lane: its token (row = wave, column = lane & 15), its piece of the 9 x 96 window
+  int y0, yp, x0, xp;
+  float h1, w1;
+  bilinear_src_dev(wave, 30.0f / 8.0f, 30, y0, yp, h1);
+  bilinear_src_dev(lane & 15, 45.0f / 16.0f, 45, x0, xp, w1);
+  const int rr = lane / 6, pc = lane - 6 * rr;           // window piece of this lane (lane < 54)
+  const int row = 2 * y0 - 3 + rr;                        // image row (-1 for the top row of wave 0)
+  const int o = row * 90 + 16 * pc - 3;                   // frame byte of the piece's first window byte
+  const int kq = lane >> 4, qi = lane & 15;
+  unsigned tk_d[5] = {0, 0, 0, 0, 0};
+  auto fetch = [&](int fb) {
+    const uint8_t* src = (const uint8_t*)a.img + (size_t)fb * 5400;
+    const int a0 = o & ~3;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int aj = a0 + 4 * j;
+      tk_d[j] = 0;
+      if (lane < 54 && row >= 0 && aj >= 0 && aj < 5400) tk_d[j] = *(const unsigned*)(src + aj);
+    }
+  };
+  if ((int)blockIdx.x < a.B) fetch(blockIdx.x);
+  for (int p = tid; p < L::IMAGE / 16; p += 512) *(i32x4*)(lds + p * 16) = *(const i32x4*)(a.image + (size_t)p * 16);
+  if (tid < (L::IMAGE % 16) / 4) ((int*)(lds + (L::IMAGE & ~15)))[tid] = ((const int*)(a.image + (L::IMAGE & ~15)))[tid];
+  __syncthreads();
+  const unsigned H1 = (unsigned)(8.0f * h1) & 7u, W1 = (unsigned)(32.0f * w1) & 31u, H0 = 8u - H1, W0 = 32u - W1;
+  const unsigned w00 = (H0 * W0) & 255u, w01 = (H0 * W1) & 255u, w10 = (H1 * W0) & 255u, w11 = (H1 * W1) & 255u;
+  const uint8_t* win = (const uint8_t*)(lds + L::IMG + wave * L::IMG_WAVE) + 2 * x0;
+  const int* tap = (const int*)(lds + L::TAP);
+  const float* cw = (const float*)(lds + L::CW);
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    // window fill: funnel-shift to 16-byte pieces, mask the border
+    {
+      const int sh = o & 3;
+      unsigned o4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o4[j] = __builtin_amdgcn_alignbyte(tk_d[j + 1], tk_d[j], sh);
+      if (pc == 0) o4[0] &= 0xff000000u;
+      if (pc == 5) o4[3] &= 0x000000ffu;
+      if (lane < 54)
+        *(i32x4*)(lds + L::IMG + wave * L::IMG_WAVE + rr * 96 + 16 * pc) = (i32x4){(int)o4[0], (int)o4[1], (int)o4[2], (int)o4[3]};
+    }
+    if (b + (int)gridDim.x < a.B) fetch(b + gridDim.x);
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the window is private to this wave
+    __builtin_amdgcn_wave_barrier();
+    float tk_pt[13];
+#pragma unroll
+    for (int s = 0; s < 13; ++s) {
+      const int off = tap[4 * s + kq];
+      const unsigned b256 = (unsigned)win[off] * w00 + (unsigned)win[off + 2] * w01 + (unsigned)win[off + 192] * w10 +
+                            (unsigned)win[off + 194] * w11;
+      tk_pt[s] = (float)b256;
+    }
+    f32x4 acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) acc[ct] = *(const f32x4*)(lds + L::CB + (EC * kq + 4 * ct) * 4);
+#pragma unroll
+    for (int s = 0; s < 13; ++s)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(cw[(s * NCT + ct) * 64 + lane], tk_pt[s], acc[ct], 0, 0, 0);
+    float xr[EC];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xr[4 * ct + i] = acc[ct][i];
+    layernorm_q16<E>(xr, lnp, lnp + E, EC * kq);
+    float* out = a.tokens + ((size_t)b * S + wave * 16 + qi) * E + EC * kq;
+#pragma unroll
+    for (int i = 0; i < EC; i += 4) *(f32x4*)(out + i) = (f32x4){xr[i], xr[i + 1], xr[i + 2], xr[i + 3]};
+    __builtin_amdgcn_wave_barrier();      // the window is rewritten for the next frame only after these reads were issued
+  }
+}
