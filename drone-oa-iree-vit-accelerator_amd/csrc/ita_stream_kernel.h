@@ -305,6 +305,55 @@ __device__ __forceinline__ void dq_group(const i32x4 (&acc)[4], float mult, floa
 #endif
 }
 
+// ---- f32 token rows in and out.  Lane (qi, kq) owns the quarter [E/4 kq, E/4 (kq+1)) of token qi's row.  Loaded or stored
+// quarter by quarter, a wave-instruction touches 64 different cache lines for 16 bytes each -- the shape one CU moves at a
+// fifth of its contiguous rate (tools/microbench/cu_fill_rows.hip).  Instead the four lanes of a token move 64 CONTIGUOUS
+// bytes per instruction (16 rows x 64 B per wave-instruction) and a 4 x 4 transpose of 16-byte items across those lanes
+// (lanes 16 and 32 apart: two rounds of v_permlane32_swap / v_permlane16_swap, 16 instructions) sorts the quarters out.
+// raw[16 jj + 4 i + c]: item i of transpose jj = floats 4 p .. 4 p + 3 of the row, p = (E/16) i + 4 jj + kq.
+template <int E>
+__device__ __forceinline__ void ld_tok_items(const float* row, int kq, float (&raw)[E / 4]) {
+  constexpr int PQ = E / 16, NJ = E / 64;
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 v = *(const f32x4*)(row + 4 * (PQ * i + 4 * jj + kq));
+      raw[16 * jj + 4 * i] = v.x; raw[16 * jj + 4 * i + 1] = v.y; raw[16 * jj + 4 * i + 2] = v.z; raw[16 * jj + 4 * i + 3] = v.w;
+    }
+}
+// in place: items (as loaded / as they will be stored) <-> this lane's quarter in channel order; its own inverse
+template <int E>
+__device__ __forceinline__ void tok_items_transpose(float (&x)[E / 4]) {
+  constexpr int NJ = E / 64;
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      unsigned i0 = __float_as_uint(x[16 * jj + c]), i1 = __float_as_uint(x[16 * jj + 4 + c]);
+      unsigned i2 = __float_as_uint(x[16 * jj + 8 + c]), i3 = __float_as_uint(x[16 * jj + 12 + c]);
+      const auto a02 = __builtin_amdgcn_permlane32_swap(i0, i2, false, false);
+      const auto a13 = __builtin_amdgcn_permlane32_swap(i1, i3, false, false);
+      const auto b01 = __builtin_amdgcn_permlane16_swap(a02[0], a13[0], false, false);
+      const auto b23 = __builtin_amdgcn_permlane16_swap(a02[1], a13[1], false, false);
+      x[16 * jj + c] = __uint_as_float(b01[0]); x[16 * jj + 4 + c] = __uint_as_float(b01[1]);
+      x[16 * jj + 8 + c] = __uint_as_float(b23[0]); x[16 * jj + 12 + c] = __uint_as_float(b23[1]);
+    }
+}
+template <int E>
+__device__ __forceinline__ void st_tok_quarter(float* row, int kq, const float (&y)[E / 4]) {
+  constexpr int PQ = E / 16, NJ = E / 64;
+  float t[E / 4];
+#pragma unroll
+  for (int i = 0; i < E / 4; ++i) t[i] = y[i];
+  tok_items_transpose<E>(t);
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *(f32x4*)(row + 4 * (PQ * i + 4 * jj + kq)) = (f32x4){t[16 * jj + 4 * i], t[16 * jj + 4 * i + 1], t[16 * jj + 4 * i + 2], t[16 * jj + 4 * i + 3]};
+}
+
 // (amdgpu_waves_per_eu(2, 2): the workgroup owns the CU's LDS, so two waves per SIMD is all there will ever be -- without
 // it the scheduler trades instruction-level parallelism for registers it has no use for: the LDS size is dynamic)
 template <int E, bool FFN, int TOK, bool STAMP = false, bool IO8 = false>
@@ -453,12 +502,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int c = 0; c < NK; ++c) xq_cur[c] = *(const i32x4*)(xrow + 16 * c);
     } else {
-      const float* xrow = a.x + ((size_t)blockIdx.x * S + wave * 16 + (ol & 15)) * E + EC * (ol >> 4);
-#pragma unroll
-      for (int i = 0; i < EC; i += 4) {
-        const f32x4 v = *(const f32x4*)(xrow + i);
-        xr[i] = v.x; xr[i + 1] = v.y; xr[i + 2] = v.z; xr[i + 3] = v.w;
-      }
+      ld_tok_items<E>(a.x + ((size_t)blockIdx.x * S + wave * 16 + (ol & 15)) * E, ol >> 4, xr);   // transposed where it is first used
     }
     if (a.h0_dst && tid < 32) {
       const size_t row = a.slots ? (size_t)a.slots[blockIdx.x] : (size_t)blockIdx.x;
@@ -500,6 +544,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (p < NW) *(i32x4*)(lds + p * 16) = vw[j];
     }
     lds_barrier();   // weights, biases and column-sum bases in place
+    if constexpr (TOK == 0 && !IO8) tok_items_transpose<E>(xr);   // the first frame's rows were fetched as items (ld_tok_items)
   }
   if (STAMP && a.stamps && (tid & 255) == 0)
     a.stamps[(((size_t)blockIdx.x * 8) * 2 + (wave >> 2)) * 16 + 13] = __builtin_amdgcn_s_memrealtime();
@@ -591,12 +636,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int c = 0; c < NK; ++c) xq_nxt[c] = *(const i32x4*)(xnrow + 16 * c);
     } else {
-      const float* xnrow = a.x + ((size_t)min(nb, a.B - 1) * S + token) * E + EC * kq;
-#pragma unroll
-      for (int i = 0; i < EC; i += 4) {
-        const f32x4 v = *(const f32x4*)(xnrow + i);
-        xn[i] = v.x; xn[i + 1] = v.y; xn[i + 2] = v.z; xn[i + 3] = v.w;
-      }
+      ld_tok_items<E>(a.x + ((size_t)min(nb, a.B - 1) * S + token) * E, kq, xn);   // items; transposed at the end of the frame
     }
 
     // ---------------- attention for this wave's 16 queries: logits and probabilities stay in registers
@@ -799,10 +839,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     {
       const size_t o = ((size_t)b * S + token) * E + EC * kq;
-      if (a.y) {
-#pragma unroll
-        for (int i = 0; i < EC; i += 4) *(f32x4*)(a.y + o + i) = (f32x4){yv[i], yv[i + 1], yv[i + 2], yv[i + 3]};
-      }
+      if (a.y) st_tok_quarter<E>(a.y + ((size_t)b * S + token) * E, kq, yv);
       if (!(ITA_ABLATE & 128) && a.y_hi) {
         typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #pragma unroll
@@ -835,6 +872,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
       if (more) tok_finish(nb, true, xr, ol);
     } else {
+      tok_items_transpose<E>(xn);
 #pragma unroll
       for (int i = 0; i < EC; ++i) xr[i] = xn[i];
     }
