@@ -981,9 +981,7 @@ __global__ __launch_bounds__(512) void ita_tok_stream_kernel(const ItaTokStreamA
 #pragma unroll
       for (int i = 0; i < 4; ++i) xr[4 * ct + i] = acc[ct][i];
     layernorm_q16<E>(xr, lnp, lnp + E, EC * kq);
-    float* out = a.tokens + ((size_t)b * S + wave * 16 + qi) * E + EC * kq;
-#pragma unroll
-    for (int i = 0; i < EC; i += 4) *(f32x4*)(out + i) = (f32x4){xr[i], xr[i + 1], xr[i + 2], xr[i + 3]};
+    st_tok_quarter<E>(a.tokens + ((size_t)b * S + wave * 16 + qi) * E, kq, xr);   // 64 contiguous bytes per token and store
     __builtin_amdgcn_wave_barrier();      // the window is rewritten for the next frame only after these reads were issued
   }
 }
