@@ -461,9 +461,7 @@ __global__ __launch_bounds__(256) void ita_lstm_layer_kernel(const ItaLstmLayerA
   __shared__ float part[4][16][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ut = blockIdx.x, f0 = blockIdx.y * 32;
-  const int r = lane & 31, h = lane >> 5;
   static_assert(NK == 4, "fragment-order operands: four k-ranges of four k-steps (K = 256)");
-  const int arow = min(f0 + r, a.B - 1);
   const size_t ao = ((size_t)((blockIdx.y * 4 + wave) * 4) * 64 + lane) * 8;   // 1 KB per wave-load, both operands
   const size_t wo = ((size_t)((ut * 4 + wave) * 4) * 64 + lane) * 8;
   f16x8 fah[NK], fal[NK], fwh[NK], fwl[NK];
@@ -474,9 +472,13 @@ __global__ __launch_bounds__(256) void ita_lstm_layer_kernel(const ItaLstmLayerA
     fwl[s] = *(const f16x8*)(a.w_lo + wo + 512 * s);
     fal[s] = *(const f16x8*)(a.a_lo + ao + 512 * s);
   }
-  // epilogue operands of this lane's (frame, unit) as well: wave q finishes unit (4h + q) of frame r
-  const int q = wave, b = f0 + r, u = ut * 8 + 4 * h + q;
-  const size_t sb = a.slots ? (size_t)a.slots[arow] : (size_t)arow;
+  // The cell update is dealt out by MEMORY layout, not by MFMA layout: thread t finishes (frame t / 8, unit t % 8), so a
+  // wave reads and writes 8 frames x 8 consecutive units = 8 row segments of 32 bytes of the (3, rows, 128) state per
+  // instruction (dealt by the C layout -- wave q = unit 4h + q of frame r -- it was 4 bytes in each of 64 lines), and
+  // one 128-byte line of the next layer's fragment-order planes.
+  const int ef = tid >> 3, eu = tid & 7;
+  const int b = f0 + ef, u = ut * 8 + eu;
+  const size_t sb = a.slots ? (size_t)a.slots[min(b, a.B - 1)] : (size_t)min(b, a.B - 1);
   const float c_prev = a.c_in[sb * 128 + u];
   const float nx_prev = a.nx_hi ? a.nx_h_in[sb * 128 + u] : 0.0f;
   const float b_i = a.bsum[u], b_f = a.bsum[128 + u], b_g = a.bsum[256 + u], b_o = a.bsum[384 + u];
@@ -493,13 +495,14 @@ __global__ __launch_bounds__(256) void ita_lstm_layer_kernel(const ItaLstmLayerA
 #pragma unroll
   for (int e = 0; e < 16; ++e) part[wave][e][lane] = acc[e];
   __syncthreads();
-  // gates e = q, 4+q, 8+q, 12+q of unit (4h + q), frame r
+  // C layout of a tile: accumulator e of lane (r, h) = gate e / 4 of unit (e % 4) + 4 h, frame r
   if (b >= a.B) return;
   float gsum[4];
+  const int pl = ef + 32 * (eu >> 2);
 #pragma unroll
   for (int gte = 0; gte < 4; ++gte) {
-    const int e = 4 * gte + q;
-    gsum[gte] = ((part[0][e][lane] + part[1][e][lane]) + part[2][e][lane]) + part[3][e][lane];
+    const int e = 4 * gte + (eu & 3);
+    gsum[gte] = ((part[0][e][pl] + part[1][e][pl]) + part[2][e][pl]) + part[3][e][pl];
   }
   const float gi = gsum[0] * a.inv_wscale + b_i, gf = gsum[1] * a.inv_wscale + b_f,
               gg = gsum[2] * a.inv_wscale + b_g, go = gsum[3] * a.inv_wscale + b_o;

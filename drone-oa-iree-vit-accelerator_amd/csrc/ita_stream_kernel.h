@@ -838,7 +838,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int i = 0; i < EC; ++i) yv[i] = x1[i];
     }
     {
-      const size_t o = ((size_t)b * S + token) * E + EC * kq;
       if (a.y) st_tok_quarter<E>(a.y + ((size_t)b * S + token) * E, kq, yv);
       if (!(ITA_ABLATE & 128) && a.y_hi) {
         typedef _Float16 h8 __attribute__((ext_vector_type(8)));
