@@ -326,6 +326,8 @@ def main():
         # measured (tools/pipeline_probe.py, bench --schedule ...): the graph replay and the library's two-thread loop give
         # the same step at 128-256 frames (43 / 50 us: what the GPU overlaps of front(t+1) and back(t)); below that the
         # graph wins (the step is launch-bound and a replay has no launches)
+        # (at 512 / 1024 frames the graph replay is also 3 % / 2 % faster than one stream, but the dominant kernel's launch
+        #  time for the roofline is then not measured inside the timed region: the default stays "stream" there)
         sched = "stream" if (B > 256 or a.image_dtype != "u8" or K % NG) else "graph"
     if sched == "pipelined" and K % 40 == 0:
         NG = 40        # steps per ita_vitlstm_pipelined call: the helper thread is started once per call
