@@ -351,7 +351,9 @@ def main():
             def __call__(self):
                 eng.pipelined(*self.args, self.sf, self.sb)     # joins on its front stream: run under torch.cuda.stream(sf)
         graph = LibPipeline()
-    if graph is not None:
+    batched_gather = graph is None and not strong
+    velring = torch.empty((2, NG, B, 3), device=dev) if batched_gather else None
+    if graph is not None or batched_gather:
         gather = itadist.VelocityGather(NG * B, world, dev)    # one all-gather per NG steps: their velocities
     torch.cuda.synchronize()
 
@@ -369,6 +371,17 @@ def main():
                         gather.start(graph.vel.reshape(NG * B, 3))
             return
         src, dst = state[i & 1], state[(i + 1) & 1]
+        if batched_gather:
+            # weak scaling, equal shards: the velocities of NG steps go out in ONE all-gather (96 KiB instead of eight times
+            # 12 KiB).  The encoder's persistent workgroups need every CU; a collective's kernel that holds one for 10-20 us
+            # delays the whole launch by that much, so the fewer collectives share the GPU with it the better.
+            half, k = (i // NG) & 1, i % NG
+            if world > 1 and k == 0:
+                gather.ready()      # the all-gather of two groups ago read this half of the velocity ring
+            eng.forward(img, dv, qt, src, out=(velring[half][k], dst[0], dst[1]))
+            if world > 1 and k == NG - 1:
+                gather.start(velring[half].reshape(NG * B, 3))
+            return
         vel = vels[i & 1]
         if world > 1:
             gather.ready()      # the all-gather of step i-2 read this velocity buffer
