@@ -260,8 +260,8 @@ def main():
                     help="strong scaling (BASELINE config 4 as written: batch = 1024 over 1 -> 8 GPUs): this many frames per "
                          "step in all, cut into contiguous per-GPU shards (dist.shard_range); overrides --frames-per-gpu")
     ap.add_argument("--image-dtype", choices=["u8", "f32"], default="u8",
-                    help="u8: the wire format of the reference host (ita_wire.h; float(pixel)/255.0f of main.cpp:168-169 "
-                         "is done on the device, bit-identically, inside the fused tokenizer+encoder kernel); "
+                    help="u8: the wire format of the reference host (ita_wire.h; the /255.0f of main.cpp:168-169 is folded into "
+                         "the conv weights of the fused tokenizer+encoder kernel, the blend done exactly on the pixel codes); "
                          "f32: the graph's own input type (stand-alone tokenizer launch, 4x the frame bytes)")
     ap.add_argument("--schedule", choices=["auto", "stream", "pipelined", "graph"], default="auto",
                     help="stream: one ita_vitlstm_forward per step on one stream.  pipelined: ita_vitlstm_pipelined, the "
