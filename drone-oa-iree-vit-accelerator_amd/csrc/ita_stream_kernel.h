@@ -21,8 +21,8 @@
 // ever waits for another wave's tile.
 //
 // LDS (E = 64, fused tokenizer): weight image 80 KB + biases/LayerNorm 5.3 KB + conv weights 13.3 KB
-// (f32 MFMA fragments) + k/255 table 1 KB | K 24 KB | V^T 24 KB | column sums | eight private 9 x 96
-// byte windows of the next frame = 159 488 B of the CU's 160 KB.
+// (f32 MFMA fragments) | K 24 KB | V^T 24 KB | column sums | eight private 9 x 96 byte windows of the next
+// frame = 161 744 B of the CU's 160 KB (163 840).  E = 128 (no tokenizer; fc1 / fc2 weights stay in global memory): 158 464 B.
 #pragma once
 #include "ita_int8_kernels.h"
 #ifndef ITA_ABLATE
