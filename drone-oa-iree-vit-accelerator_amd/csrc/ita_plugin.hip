@@ -1408,8 +1408,10 @@ int ita_vitlstm_pipelined(ita_handle h, const void* const* image, int image_dtyp
   std::thread back_thread([&]() {
     for (int t = 0; t < n_steps; ++t) {
       const int buf = t % ITA_PART_BUFFERS;
-      while (fronts_recorded.load(std::memory_order_acquire) <= t)
+      while (fronts_recorded.load(std::memory_order_acquire) <= t) {
         if (abort_flag.load(std::memory_order_relaxed)) return;
+        std::this_thread::yield();
+      }
       if (hipStreamWaitEvent(sb, evf[buf], 0) != hipSuccess) { rc_back = fail(ITA_ERR_HIP, "hipStreamWaitEvent (back stream)"); break; }
       if ((rc_back = ita_vitlstm_back(h, desvel[t], quat[t], sh[t & 1], sc[t & 1], vel[t], sh[(t + 1) & 1], sc[(t + 1) & 1], batch,
                                       buf, sb)))
@@ -1422,7 +1424,8 @@ int ita_vitlstm_pipelined(ita_handle h, const void* const* image, int image_dtyp
   for (int t = 0; t < n_steps && !rc; ++t) {
     const int buf = t % ITA_PART_BUFFERS;
     if (t >= ITA_PART_BUFFERS) {   // front(t) overwrites what back(t - NB) read
-      while (backs_recorded.load(std::memory_order_acquire) <= t - ITA_PART_BUFFERS && !abort_flag.load(std::memory_order_relaxed)) {}
+      while (backs_recorded.load(std::memory_order_acquire) <= t - ITA_PART_BUFFERS && !abort_flag.load(std::memory_order_relaxed))
+        std::this_thread::yield();
       if (abort_flag.load(std::memory_order_relaxed)) break;
       if (hipStreamWaitEvent(sf, evb[buf], 0) != hipSuccess) { rc = fail(ITA_ERR_HIP, "hipStreamWaitEvent (front stream)"); break; }
     }
