@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Counted instruction budget of the encoder kernel's frame loop, from the ISA hipcc emits for gfx950 (no GPU needed).
+Compiles csrc/ita_plugin.hip to assembly, takes ita_stream_kernel<64, true, 1> from its frame-loop header to the end of the
+function (the loop body; inline-asm requantisation blocks are expanded in the assembly) and groups the opcodes.
+Counts are per WAVE and frame; a frame is 8 waves.  usage: python tools/valu_budget.py"""
+import collections, os, re, subprocess, sys, tempfile
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(REPO, "drone-oa-iree-vit-accelerator_amd", "csrc", "ita_plugin.hip")
+KERNEL = "_Z17ita_stream_kernelILi64ELb1ELi1ELb0ELb0EEv13ItaStreamArgs"
+CLASSES = [
+    ("requantise: unbias + scale (v_pk_add/mul_f32)", r"^v_pk_(add|mul)_f32"),
+    ("requantise: clamp (v_med3_f32)", r"^v_med3_f32"),
+    ("requantise: round + byte insert (SDWA add)", r"^v_add_f32_sdwa"),
+    ("integer softmax (packed 16-bit)", r"^v_pk_.*(i16|u16|b16)|^v_dot4|^v_rndne|^v_permlane|^v_cndmask"),
+    ("float: LayerNorm, residuals, dequantise, f16 split", r"^v_(add|sub|mul|fma|fmac|rcp|rsq|sqrt|div|pk_fma|cvt_pk_f16|cvt_f16|cvt_f32_f16|max|min)_?"),
+    ("tokenizer blend / window (integer)", r"^v_(mul_u32_u24|mad_u32_u24|alignbyte|alignbit|cvt_f32_u32|bfe|and_b32|or_b32|lshl|lshr|add_u32|add3|lshl_add|perm)"),
+    ("moves", r"^v_mov|^v_accvgpr|^v_readfirstlane"),
+]
+
+
+def main():
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I",
+                               os.path.join(REPO, "include"), "--cuda-device-only", "-S", "-o", out, SRC],
+                              stderr=subprocess.DEVNULL)
+        lines = open(out).read().split("\n")
+    beg = next(i for i, l in enumerate(lines) if l.startswith(KERNEL + ":"))
+    end = next(i for i in range(beg, len(lines)) if "s_endpgm" in lines[i])
+    body = lines[beg:end]
+    hdr = next(i for i, l in enumerate(body) if re.match(r"\.LBB\d+_\d+:.*Loop Header", l))
+    ops = collections.Counter()
+    for l in body[hdr:]:
+        l = l.strip()
+        if not l or l[0] in ";." or l.endswith(":"):
+            continue
+        ops[l.split()[0]] += 1
+    valu = {k: v for k, v in ops.items() if k.startswith("v_") and not k.startswith("v_mfma")}
+    total = sum(valu.values())
+    print(f"ita_stream_kernel<64, true, 1> frame loop, per wave and frame: {sum(ops.values())} instructions")
+    print(f"  VALU {total}   MFMA i8 {ops.get('v_mfma_i32_16x16x64_i8', 0)}   MFMA f32 {ops.get('v_mfma_f32_16x16x4_f32', 0)}   "
+          f"LDS {sum(v for k, v in ops.items() if k.startswith('ds_'))}   VMEM {sum(v for k, v in ops.items() if k.startswith(('global_', 'buffer_', 'flat_')))}   "
+          f"SALU/other {sum(v for k, v in ops.items() if k.startswith('s_'))} (s_nop {ops.get('s_nop', 0)}, s_waitcnt {ops.get('s_waitcnt', 0)})")
+    left = dict(valu)
+    print(f"  {'VALU class':58s} {'per wave':>9s} {'per frame':>10s} {'share':>6s}")
+    for name, pat in CLASSES:
+        n = sum(v for k, v in left.items() if re.match(pat, k))
+        left = {k: v for k, v in left.items() if not re.match(pat, k)}
+        print(f"  {name:58s} {n:9d} {8 * n:10d} {100.0 * n / total:5.1f}%")
+    n = sum(left.values())
+    print(f"  {'other (' + ', '.join(sorted(left, key=left.get, reverse=True)[:4]) + ' ...)':58s} {n:9d} {8 * n:10d} {100.0 * n / total:5.1f}%")
+    print(f"  {'all':58s} {total:9d} {8 * total:10d}")
+
+
+if __name__ == "__main__":
+    main()
