@@ -250,6 +250,41 @@ def bench_c5(frames=32, out_ch=48, iters=20):
             "timing": f"torch events over {iters} back-to-back launches on the launch stream"}
 
 
+def bench_vit2l(frames=1024, iters=50):
+    """The reference's second graph family (models/ITA/QAT/model.py:22-87: E = 128, two encoder layers, no fusion tail,
+    decoder on the flattened tokens), whole forward with carried state, from the committed fixture's weights."""
+    import glob
+    import torch
+    from drone_oa_iree_vit_accelerator_amd import host, params, synth
+    fx = sorted(glob.glob(os.path.join(REPO, "tests", "golden", "vit2l_*.npz")))
+    if not fx:
+        return None
+    d = params.load_fixture(fx[0])
+    fp = synth.float_params(int(d["meta.seed"]), E=128, num_layers=2, tail=False)
+    eng = host.Engine(params.blob_from_record(d, fp, E=128, num_layers=2), device=torch.cuda.current_device(), reserve=frames)
+    fr = synth.frames(11, frames)
+    img, dv, qt = (torch.from_numpy(fr[k]).cuda() for k in ("img_u8", "desvel", "quat"))
+    state = [(torch.zeros((3, frames, 128), device="cuda"), torch.zeros((3, frames, 128), device="cuda")) for _ in range(2)]
+    vel = torch.empty((frames, 3), device="cuda")
+    for i in range(10):
+        eng.forward(img, dv, qt, state[i & 1], out=(vel, *state[(i + 1) & 1]))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(iters):
+        eng.forward(img, dv, qt, state[i & 1], out=(vel, *state[(i + 1) & 1]))
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    eng.close()
+    # int8 ops per frame: two layers of (attention E = 128: 2 x (3 x 128 x 128 x 192 + 2 x 128 x 128 x 192 + 128 x 192 x 128) = 37.75 M,
+    # FFN 128 -> 256 -> 128: 2 x 2 x 128 x 128 x 256 = 16.78 M)
+    ops = 2 * (2 * (3 * 128 * 128 * 192 + 2 * 128 * 128 * 192 + 128 * 192 * 128) + 2 * 2 * 128 * 128 * 256)
+    return {"workload": f"ITA two-layer E=128 graph without fusion tail (models/ITA/QAT/model.py), end-to-end forward, {frames} u8 frames, "
+                        "state carried", "frames": frames, "ms_per_step": round(ms, 5), "frames_per_s": round(frames / ms * 1e3, 1),
+            "kernels": "ita_tok_stream_kernel<128>, 2 x ita_stream_kernel<128, true, 0>, folded GEMM K = 16384, LSTM, fc",
+            "int8_frac_of_step": round(ops * frames / (ms * 1e-3) / 5e15, 4),
+            "timing": f"wall clock over {iters} forwards, one stream"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -537,6 +572,9 @@ def main():
             del graph
             eng.close()
             out["configs"] = {"c2": bench_c2(), "c5": bench_c5()}
+            v2 = bench_vit2l()
+            if v2:
+                out["configs"]["vit2l"] = v2
     fence()
     if rank == 0:
         print(json.dumps(out), flush=True)
