@@ -479,7 +479,7 @@ def test_tail_from_reference_x2_within_1e4(torch_cuda, oracle, path):
     eng.close()
 
 
-FIX_2L = golden_files("vit2l_*.npz")
+FIX_2L = golden_files("vit2l_*.npz") + golden_files("vit1l_*.npz")
 
 
 @pytest.mark.parametrize("mode", [1, 0], ids=["tail_f16x3", "tail_exact_f32"])
@@ -492,8 +492,9 @@ def test_two_layer_e128_no_tail_graph(torch_cuda, oracle, path, mode):
     the reference's own fixture within the end-to-end int8 bound."""
     torch = torch_cuda
     d = params.load_fixture(path)
-    fp = synth.float_params(int(d["meta.seed"]), E=128, num_layers=2, tail=False)
-    blob = params.blob_from_record(d, fp, E=128, num_layers=2)
+    nl = int(d["meta.num_layers"])      # 2: models/ITA/QAT/model.py; 1: models/ITA_single_layer/QAT/model.py
+    fp = synth.float_params(int(d["meta.seed"]), E=128, num_layers=nl, tail=False)
+    blob = params.blob_from_record(d, fp, E=128, num_layers=nl)
     eng = host.Engine(blob, device=0)
     eng.set_tail_mode(mode)
     cu = lambda a: torch.from_numpy(a).cuda()

@@ -195,19 +195,20 @@ def test_full_forward_two_steps(oracle, path):
     np.testing.assert_allclose(vel0f, d["s0.vel"], atol=5e-4, rtol=0)
 
 
-FIX_2L = golden_files("vit2l_*.npz")
+FIX_2L = golden_files("vit2l_*.npz") + golden_files("vit1l_*.npz")
 
 
 @pytest.mark.parametrize("path", FIX_2L, ids=_ids(FIX_2L))
 def test_two_layer_no_tail_graph(oracle, path):
-    """The second graph family (models/ITA/QAT/model.py:22-87): E = 128, two encoder layers, no fusion tail -- the
-    decoder reads the flattened tokens.  Fixture = the reference's own module run through its QAT flow
-    (tools/gen_golden.py: gen_vit2l).  Same bounds as the ITAViTLSTM fixtures: float stages 2e-5, end to end 5e-4
+    """The second graph family: E = 128, no fusion tail -- the decoder reads the flattened tokens -- with two encoder layers
+    (models/ITA/QAT/model.py:22-87) and with one (models/ITA_single_layer/QAT/model.py:30-101).  Fixtures = the reference's own
+    modules run through its QAT flow (tools/gen_golden.py: gen_vit2l, gen_vit1l).  Same bounds as the ITAViTLSTM fixtures: float stages 2e-5, end to end 5e-4
     (an int8 code can flip behind a float LayerNorm), isolated flips only."""
     d = params.load_fixture(path)
-    fp = synth.float_params(int(d["meta.seed"]), E=128, num_layers=2, tail=False)
+    nl = int(d["meta.num_layers"])
+    fp = synth.float_params(int(d["meta.seed"]), E=128, num_layers=nl, tail=False)
     assert synth.digest(fp) == str(d["meta.params_sha256"])
-    blob = params.blob_from_record(d, fp, E=128, num_layers=2)
+    blob = params.blob_from_record(d, fp, E=128, num_layers=nl)
     assert np.frombuffer(blob[8 + 4 * 7:8 + 4 * 8], np.int32)[0] == 0           # has_tail = 0
     # layer 0 block by block from the reference's own block inputs: bit-exact int8 codes
     t0 = params.attention_tensors(d, "attn0.", 0)
@@ -217,7 +218,7 @@ def test_two_layer_no_tail_graph(oracle, path):
     assert (tp["out_q"] != d["s0.attn0.out_q"]).mean() < 2e-3                    # near-tie logits only (see test_mha)
     vel0, h0, c0, tpf = oracle.forward(blob, d["in0.img_u8"], d["in0.desvel"], d["in0.quat"], taps=True)
     np.testing.assert_allclose(tpf["tokens"], d["s0.tok.out"], atol=2e-5, rtol=0)
-    assert np.mean(np.abs(tpf["x2"] - d["s0.x2_1"]) > 1e-4) < 5e-3
+    assert np.mean(np.abs(tpf["x2"] - d[f"s0.x2_{nl - 1}"]) > 1e-4) < 5e-3
     np.testing.assert_allclose(tpf["dec"], d["s0.dec"], atol=5e-3, rtol=0)
     for got, key in ((vel0, "s0.vel"), (h0, "s0.h"), (c0, "s0.c")):
         np.testing.assert_allclose(got, d[key], atol=5e-4, rtol=0, err_msg=key)

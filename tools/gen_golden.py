@@ -257,6 +257,62 @@ def gen_vit2l(seed, B, out_dir):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def gen_vit1l(seed, B, out_dir):
+    """models/ITA_single_layer/QAT/model.py:30-101 -- the single-layer member of the no-tail family: E = 128, ONE encoder
+    layer (attributes attention_block / ffn_block / norm1 / norm2, no lists), decoder Linear(E*S -> 512) and nn_fc2 under
+    spectral_norm (removed on the instance, as in gen_float_twin, so that the synthetic weights are the effective ones).
+    Same QAT flow and the same record layout as gen_vit2l with num_layers = 1."""
+    from models.ITA_single_layer.QAT.model import ITALSTMNetVIT_QAT as ITAViT1L
+    fp = synth.float_params(seed, E=128, num_layers=1, tail=False)
+    model = ITAViT1L()
+    for lin in (model.decoder, model.nn_fc2):
+        torch.nn.utils.remove_spectral_norm(lin)
+        lin._load_state_dict_pre_hooks.clear()   # the removal leaves spectral_norm's load hook behind (it demands weight_orig)
+    ren = lambda k: (k.replace("attention_blocks.0.", "attention_block.").replace("ffn_blocks.0.", "ffn_block.")
+                      .replace("norms1.0.", "norm1.").replace("norms2.0.", "norm2."))
+    sd = model.state_dict()
+    for k, v in fp.items():
+        assert ren(k) in sd and tuple(sd[ren(k)].shape) == v.shape, k
+    model.load_state_dict({ren(k): torch.from_numpy(v) for k, v in fp.items()}, strict=True)
+    model.attention_block.qconfig = ita_symmetric_qconfig     # training/qa_train.py:67-68
+    model.ffn_block.qconfig = ita_symmetric_qconfig
+    prepared = torch.ao.quantization.prepare_qat(model.train())
+    prepared.lstm.dropout = 0.0
+    with torch.no_grad():
+        for it in range(4):
+            prepared(to_X(synth.frames(100 * seed + 80 + it, 8, gain=0.8)))
+    conv = torch.ao.quantization.convert(prepared.eval())
+    conv.attention_block.matmul2.matmul = patched_matmul2(conv.attention_block.matmul2.scale, conv.attention_block.matmul2.zero_point)
+    tap = Tap()
+    tap.add(conv.tokenizer, "tok.out")
+    tap_attention(tap, conv.attention_block, "attn0.")
+    tap_ffn(tap, conv.ffn_block, "ffn0.")
+    tap.add(conv.norm1, "x1_0")
+    tap.add(conv.norm2, "x2_0")
+    tap.add(conv.decoder, "dec")
+    fr0, fr1 = synth.frames(10 * seed + 7, B), synth.frames(10 * seed + 8, B)
+    with torch.no_grad():
+        vel0, (h0, c0) = conv(to_X(fr0, None))
+        stage = dict(tap.t)
+        vel1, (h1, c1) = conv(to_X(fr1, (h0, c0)))
+    rec = {"meta.seed": np.int64(seed), "meta.B": np.int64(B), "meta.E": np.int64(128), "meta.num_layers": np.int64(1),
+           "meta.params_sha256": np.array(synth.digest(fp)), "meta.torch": np.array(torch.__version__),
+           "meta.engine": np.array("qnnpack")}
+    rec.update(block_quant_record("attn0.", attn=conv.attention_block))
+    rec.update(block_quant_record("ffn0.", ffn=conv.ffn_block))
+    for k, v in fr0.items():
+        rec["in0." + k] = v
+    for k, v in fr1.items():
+        rec["in1." + k] = v
+    for k in ("tok.out", "x1_0", "x2_0", "dec", "attn0.x_q", "attn0.probs", "attn0.out_q", "ffn0.h1_relu", "ffn0.out_q"):
+        rec["s0." + k] = stage[k]
+    rec["s0.vel"] = vel0.numpy(); rec["s0.h"] = h0.numpy(); rec["s0.c"] = c0.numpy()
+    rec["s1.vel"] = vel1.numpy(); rec["s1.h"] = h1.numpy(); rec["s1.c"] = c1.numpy()
+    path = os.path.join(out_dir, f"vit1l_E128_s{seed}_B{B}.npz")
+    np.savez_compressed(path, **rec)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 class _Blocks(torch.nn.Module):
     """container so that prepare_qat/convert see the reference blocks as children"""
 
@@ -411,7 +467,7 @@ def gen_float_twin(seed, B, out_dir):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
-    ap.add_argument("--only", default="", help="comma list of: softmax, vitlstm, blocks, tail_large, float_twin, vit2l (default: all)")
+    ap.add_argument("--only", default="", help="comma list of: softmax, vitlstm, blocks, tail_large, float_twin, vit2l, vit1l (default: all)")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     only = set(filter(None, a.only.split(",")))
@@ -425,9 +481,11 @@ def main():
         if "tail_large" in only: gen_tail_large(a.out)
         if "float_twin" in only: gen_float_twin(0, 2, a.out)
         if "vit2l" in only: gen_vit2l(0, 2, a.out)
+        if "vit1l" in only: gen_vit1l(0, 2, a.out)
         return
     gen_float_twin(0, 2, a.out)
     gen_vit2l(0, 2, a.out)
+    gen_vit1l(0, 2, a.out)
     gen_softmax(a.out)
     for seed in (0, 1, 2):
         gen_vitlstm(seed, 2, a.out)
