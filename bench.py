@@ -19,7 +19,9 @@ Prints ONE JSON line (rank 0).  Extra objects:
                 PyTorch f32 eager (kind "torch-f32-eager": what the reference's llvm-cpu .vmfb holds) and, under "port", the
                 scalar int8 oracle (oracle/ita_oracle.c), one process per core and one core alone
   configs       c2: BASELINE config 2 (int8 MHA block alone: B = 1 latency, 1024-frame int8 MFMA fraction);
-                c5: BASELINE config 5 (fusion tail on a 64x128 token grid: MFMA and HBM fractions), same run (N = 1 only)
+                c5: BASELINE config 5 (fusion tail on a 64x128 token grid: MFMA and HBM fractions), same run (N = 1 only);
+                vit2l: the second graph family (E = 128, two layers, no fusion tail), whole forward at 1024 frames
+--schedule selects one stream / the library's two-stream pipeline / its HIP-graph form (default: graph up to 256 frames per GPU).
 --global-batch G gives the strong-scaling form of config 4 (G frames per step cut over the GPUs, "scaling": "strong").
 """
 import argparse
