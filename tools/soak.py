@@ -39,8 +39,31 @@ def main():
             print(f"{i + 1} forwards, {bad} mismatching checks, {time.time() - t0:.1f} s", flush=True)
     torch.cuda.synchronize()
     print("soak:", "OK" if bad == 0 else f"{bad} MISMATCHES", f"({n} forwards of {B} frames)")
+    # the library's two-thread, two-stream pipeline (ita_vitlstm_pipelined): 12 time steps of 130 streams, repeated; every
+    # call must reproduce the sequential forwards bit for bit (host-side event ordering between the two threads)
+    Bp, steps, calls = 130, 12, max(20, n // 100)
+    frs = [synth.frames(700 + t, Bp) for t in range(steps)]
+    imgs = [torch.from_numpy(f["img_u8"]).cuda() for f in frs]
+    dvs = [torch.from_numpy(f["desvel"]).reshape(Bp).cuda() for f in frs]
+    qts = [torch.from_numpy(f["quat"]).cuda() for f in frs]
+    h0, c0 = h[:, :Bp].contiguous(), c[:, :Bp].contiguous()
+    st, want = (h0, c0), []
+    for t in range(steps):
+        v, st = eng.forward(imgs[t], dvs[t], qts[t], st)
+        want.append(v.clone())
+    sf, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    badp = 0
+    for _ in range(calls):
+        hh, cc = h0.clone(), c0.clone()
+        vels = [torch.empty((Bp, 3), device="cuda") for _ in range(steps)]
+        torch.cuda.synchronize()
+        eng.pipelined(imgs, dvs, qts, (hh, cc), vels, sf, sb)
+        sf.synchronize()
+        if not (all(torch.equal(vels[t], want[t]) for t in range(steps)) and torch.equal(hh, st[0]) and torch.equal(cc, st[1])):
+            badp += 1
+    print("pipelined soak:", "OK" if badp == 0 else f"{badp} MISMATCHES", f"({calls} calls of {steps} steps, {Bp} frames)")
     eng.close()
-    sys.exit(1 if bad else 0)
+    sys.exit(1 if (bad or badp) else 0)
 
 
 if __name__ == "__main__":
