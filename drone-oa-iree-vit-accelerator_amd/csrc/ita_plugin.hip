@@ -71,7 +71,8 @@ struct ita_context {
   const float *tail_b = nullptr, *dec_w = nullptr, *dec_b = nullptr, *fc_w = nullptr, *fc_b = nullptr;
   // derived device buffers
   float* tail_wT = nullptr;
-  char* tok_simg = nullptr;                // LDS image of ita_tok_stream_kernel (u8 wire frames)
+  char* tok_simg = nullptr;                // LDS images of ita_tok_stream_kernel: [u8 frames (conv weights x 1/65280) | f32 frames]
+  size_t tok_simg_bytes = 0;               // size of one of the two
   float* tok_wT = nullptr;                 // [2][50][E] conv7x7 weights k-major, row 49 = 0; second copy x 1/65280 (u8 frames)
   float* wcat[3] = {nullptr, nullptr, nullptr};
   float* bsum[3] = {nullptr, nullptr, nullptr};
@@ -481,11 +482,16 @@ int launch_tokenizer(ita_context* c, const void* img, int dtype, float* tokens, 
   static const int tok_dbg = getenv("ITA_TOK_DBG") ? atoi(getenv("ITA_TOK_DBG")) : 0;
   const bool u8 = dtype == ITA_IMAGE_U8;
   static const bool block_tok = getenv("ITA_TOK_BLOCK_KERNEL") != nullptr;   // diagnostic: the older tokenizer kernel for u8 frames too
-  if (u8 && c->tok_simg && !block_tok) {
-    ItaTokStreamArgs ta{c->tok_simg, img, tokens, B};
+  if (c->tok_simg && !block_tok) {
+    ItaTokStreamArgs ta{c->tok_simg + (u8 ? 0 : c->tok_simg_bytes), img, tokens, B};
     const int g = B < c->num_cus ? B : c->num_cus;
-    if (c->hdr.E == 64) hipLaunchKernelGGL(ita_tok_stream_kernel<64>, dim3(g), dim3(512), ItaTokStreamLds<64>::TOTAL, s, ta);
-    else hipLaunchKernelGGL(ita_tok_stream_kernel<128>, dim3(g), dim3(512), ItaTokStreamLds<128>::TOTAL, s, ta);
+    if (c->hdr.E == 64) {
+      if (u8) hipLaunchKernelGGL((ita_tok_stream_kernel<64, true>), dim3(g), dim3(512), (ItaTokStreamLds<64, true>::TOTAL), s, ta);
+      else hipLaunchKernelGGL((ita_tok_stream_kernel<64, false>), dim3(g), dim3(512), (ItaTokStreamLds<64, false>::TOTAL), s, ta);
+    } else {
+      if (u8) hipLaunchKernelGGL((ita_tok_stream_kernel<128, true>), dim3(g), dim3(512), (ItaTokStreamLds<128, true>::TOTAL), s, ta);
+      else hipLaunchKernelGGL((ita_tok_stream_kernel<128, false>), dim3(g), dim3(512), (ItaTokStreamLds<128, false>::TOTAL), s, ta);
+    }
     HIPCHK(hipGetLastError());
     return ITA_OK;
   }
@@ -735,8 +741,10 @@ int ita_create(ita_handle* out, int device_ordinal) {
   if ((rc = set_lds(ita_mha_kernel<128>, ItaMhaLds<128>::TOTAL))) { delete c; return rc; }
   if ((rc = set_lds(ita_ffn_kernel<64>, ItaFfnLds<64>::TOTAL))) { delete c; return rc; }
   if ((rc = set_lds(ita_ffn_kernel<128>, ItaFfnLds<128>::TOTAL))) { delete c; return rc; }
-  if ((rc = set_lds(ita_tok_stream_kernel<64>, ItaTokStreamLds<64>::TOTAL))) { delete c; return rc; }
-  if ((rc = set_lds(ita_tok_stream_kernel<128>, ItaTokStreamLds<128>::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_tok_stream_kernel<64, true>, ItaTokStreamLds<64, true>::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_tok_stream_kernel<128, true>, ItaTokStreamLds<128, true>::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_tok_stream_kernel<64, false>, ItaTokStreamLds<64, false>::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_tok_stream_kernel<128, false>, ItaTokStreamLds<128, false>::TOTAL))) { delete c; return rc; }
   if ((rc = set_lds(ita_tokenizer_kernel<64, true>, ita_tok_lds_bytes<64>()))) { delete c; return rc; }
   if ((rc = set_lds(ita_tokenizer_kernel<64, false>, ita_tok_lds_bytes<64>()))) { delete c; return rc; }
   if ((rc = set_lds(ita_tokenizer_kernel<128, true>, ita_tok_lds_bytes<128>()))) { delete c; return rc; }
@@ -889,18 +897,24 @@ int ita_load_weights(ita_handle h, const void* blob, size_t nbytes) {
     const float *cb = hptr<float>(h, "tok.conv_b"), *lw = hptr<float>(h, "tok.ln_w"), *lb = hptr<float>(h, "tok.ln_b");
     if (cb && lw && lb && (Ei == 64 || Ei == 128)) {   // the LDS image of ita_tok_stream_kernel<E>
       const int nct = Ei / 16, off_cw = 2 * Ei * 4, off_cb = off_cw + 13 * nct * 64 * 4, off_tap = off_cb + Ei * 4;
-      std::vector<char> im((size_t)off_tap + 52 * 4, 0);
-      memcpy(im.data(), lw, Ei * 4); memcpy(im.data() + Ei * 4, lb, Ei * 4);
-      float* cwf = (float*)(im.data() + off_cw);
-      for (int st = 0; st < 13; ++st)
-        for (int ct = 0; ct < nct; ++ct)
-          for (int lane = 0; lane < 64; ++lane) {
-            const int t = 4 * st + (lane >> 4), rho = lane & 15, ch = (Ei / 4) * (rho >> 2) + 4 * ct + (rho & 3);
-            cwf[(st * nct + ct) * 64 + lane] = t < 49 ? cw[(size_t)ch * 49 + t] * (1.0f / 65280.0f) : 0.0f;
-          }
-      memcpy(im.data() + off_cb, cb, Ei * 4);
-      int32_t* tap = (int32_t*)(im.data() + off_tap);
-      for (int t = 0; t < 52; ++t) tap[t] = t < 49 ? (t / 7) * 96 + (t % 7) : 0;
+      const size_t one = (size_t)off_tap + 52 * 4;
+      std::vector<char> im(2 * one, 0);      // [0]: u8 frames (weights x 1/65280: integer blend), [1]: f32 frames
+      for (int v = 0; v < 2; ++v) {
+        char* b0 = im.data() + v * one;
+        memcpy(b0, lw, Ei * 4); memcpy(b0 + Ei * 4, lb, Ei * 4);
+        float* cwf = (float*)(b0 + off_cw);
+        for (int st = 0; st < 13; ++st)
+          for (int ct = 0; ct < nct; ++ct)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int t = 4 * st + (lane >> 4), rho = lane & 15, ch = (Ei / 4) * (rho >> 2) + 4 * ct + (rho & 3);
+              const float wv = t < 49 ? cw[(size_t)ch * 49 + t] : 0.0f;
+              cwf[(st * nct + ct) * 64 + lane] = v == 0 ? wv * (1.0f / 65280.0f) : wv;
+            }
+        memcpy(b0 + off_cb, cb, Ei * 4);
+        int32_t* tap = (int32_t*)(b0 + off_tap);
+        for (int t = 0; t < 52; ++t) tap[t] = t < 49 ? (t / 7) * 96 + (t % 7) : 0;
+      }
+      h->tok_simg_bytes = one;
       HIPCHK(hipMalloc(&h->tok_simg, im.size()));
       HIPCHK(hipMemcpy(h->tok_simg, im.data(), im.size(), hipMemcpyHostToDevice));
     }

@@ -881,34 +881,38 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef ITA_SSTAMP
 }
 
-// ------------------------------------------------------------------ the tokenizer of u8 wire frames on its own
-// OverlapPatchMerging (reference models/ITA/QAT/layers.py:39-45) with the arithmetic of the fused tokenizer above -- per-wave
-// 9-row pixel windows, the exact integer blend of the pixel codes as the lane's own MFMA B operand, conv weights
-// x 1/65280 as v_mfma_f32_16x16x4_f32 A fragments, LayerNorm in registers -- for the cases the fused form does not cover:
-// E = 128 (its encoder kernel has no LDS left for the 27 KB of conv fragments) and callers of ita_tokenizer.  Wave w = token
-// row w of the 8 x 16 grid; one persistent 512-thread workgroup per CU, the next frame's pixels requested a frame ahead.
-// Same results as ita_tokenizer_kernel<E, true> bit for bit (same operation order), at a quarter of its time.
-template <int E>
+// ------------------------------------------------------------------ the tokenizer on its own
+// OverlapPatchMerging (reference models/ITA/QAT/layers.py:39-45) with the structure of the fused tokenizer above -- per-wave
+// 9-row pixel windows, the blended taps as the lane's own MFMA B operand, conv weights as v_mfma_f32_16x16x4_f32 A fragments,
+// LayerNorm in registers -- for the cases the fused form does not cover: E = 128 (its encoder kernel has no LDS left for
+// the 27 KB of conv fragments), f32 frames (module.main_graph's own input type: four times the window bytes) and callers of
+// ita_tokenizer.  Wave w = token row w of the 8 x 16 grid; one persistent 512-thread workgroup per CU, the next frame's
+// pixels requested a frame ahead.
+//   U8  : the exact integer blend of the pixel codes, conv weights x 1/65280 (oracle: ita_oracle_tokenizer_u8);
+//   !U8 : the oracle's float blend  h0 (w0 a + w1 b) + h1 (w0 c + w1 d)  of pixels already scaled by the caller
+//         (ita_oracle_tokenizer), conv weights as they are.
+// Same results as ita_tokenizer_kernel<E, U8> bit for bit (same operation order), at a fraction of its time.
+template <int E, bool U8>
 struct ItaTokStreamLds {
   static constexpr int NCT = E / 16;                           // 16-channel output tiles
   static constexpr int LNP = 0;                                // f32: ln_w | ln_b
-  static constexpr int CW = LNP + 2 * E * 4;                   // f32 [13][NCT][64]: conv weights x 1/65280 as A fragments
+  static constexpr int CW = LNP + 2 * E * 4;                   // f32 [13][NCT][64]: conv weights (U8: x 1/65280) as A fragments
   static constexpr int CB = CW + 13 * NCT * 64 * 4;            // f32 [E]
   static constexpr int TAP = CB + E * 4;                       // int32 [52]
   static constexpr int IMAGE = TAP + 52 * 4;
-  static constexpr int IMG = (IMAGE + 15) & ~15;               // u8 [8 waves][9][96]
-  static constexpr int IMG_WAVE = 9 * 96;
+  static constexpr int IMG = (IMAGE + 15) & ~15;               // [8 waves][9][96] pixels (u8 or f32), 3 zero columns each side
+  static constexpr int IMG_WAVE = 9 * 96 * (U8 ? 1 : 4);
   static constexpr int TOTAL = IMG + 8 * IMG_WAVE;
 };
 struct ItaTokStreamArgs {
-  const char* image;     // device copy of the LDS image (ItaTokStreamLds<E>::IMAGE bytes)
-  const void* img;       // (B,60,90) u8
+  const char* image;     // device copy of the LDS image (ItaTokStreamLds<E, U8>::IMAGE bytes)
+  const void* img;       // (B,60,90) u8 or f32
   float* tokens;         // (B,128,E)
   int B;
 };
-template <int E>
+template <int E, bool U8>
 __global__ __launch_bounds__(512) void ita_tok_stream_kernel(const ItaTokStreamArgs a) {
-  using L = ItaTokStreamLds<E>;
+  using L = ItaTokStreamLds<E, U8>;
   constexpr int S = 128, EC = E / 4, NCT = L::NCT;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -919,41 +923,57 @@ __global__ __launch_bounds__(512) void ita_tok_stream_kernel(const ItaTokStreamA
   float h1, w1;
   bilinear_src_dev(wave, 30.0f / 8.0f, 30, y0, yp, h1);
   bilinear_src_dev(lane & 15, 45.0f / 16.0f, 45, x0, xp, w1);
-  const int rr = lane / 6, pc = lane - 6 * rr;           // window piece of this lane (lane < 54)
+  const int rr = lane / 6, pc = lane - 6 * rr;           // u8: window piece of this lane (lane < 54)
   const int row = 2 * y0 - 3 + rr;                        // image row (-1 for the top row of wave 0)
   const int o = row * 90 + 16 * pc - 3;                   // frame byte of the piece's first window byte
   const int kq = lane >> 4, qi = lane & 15;
+  // f32 frames: window element e = lane + 64 j (j < 14) = (window row e / 96, window column e % 96)
+  constexpr int NF = U8 ? 1 : 14;
   unsigned tk_d[5] = {0, 0, 0, 0, 0};
+  float tk_f[NF];
   auto fetch = [&](int fb) {
-    const uint8_t* src = (const uint8_t*)a.img + (size_t)fb * 5400;
-    const int a0 = o & ~3;
+    if constexpr (U8) {
+      const uint8_t* src = (const uint8_t*)a.img + (size_t)fb * 5400;
+      const int a0 = o & ~3;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const int aj = a0 + 4 * j;
-      tk_d[j] = 0;
-      if (lane < 54 && row >= 0 && aj >= 0 && aj < 5400) tk_d[j] = *(const unsigned*)(src + aj);
+      for (int j = 0; j < 5; ++j) {
+        const int aj = a0 + 4 * j;
+        tk_d[j] = 0;
+        if (lane < 54 && row >= 0 && aj >= 0 && aj < 5400) tk_d[j] = *(const unsigned*)(src + aj);
+      }
+    } else {
+      const float* src = (const float*)a.img + (size_t)fb * 5400;
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const int e = lane + 64 * j, wr = e / 96, wc = e - 96 * wr;
+        const int iy = 2 * y0 - 3 + wr, ix = wc - 3;
+        tk_f[j] = 0.0f;
+        if (e < 9 * 96 && iy >= 0 && iy < 60 && ix >= 0 && ix < 90) tk_f[j] = src[iy * 90 + ix];
+      }
     }
   };
   if ((int)blockIdx.x < a.B) fetch(blockIdx.x);
   for (int p = tid; p < L::IMAGE / 16; p += 512) *(i32x4*)(lds + p * 16) = *(const i32x4*)(a.image + (size_t)p * 16);
-  if (tid < (L::IMAGE % 16) / 4) ((int*)(lds + (L::IMAGE & ~15)))[tid] = ((const int*)(a.image + (L::IMAGE & ~15)))[tid];
   __syncthreads();
   const unsigned H1 = (unsigned)(8.0f * h1) & 7u, W1 = (unsigned)(32.0f * w1) & 31u, H0 = 8u - H1, W0 = 32u - W1;
   const unsigned w00 = (H0 * W0) & 255u, w01 = (H0 * W1) & 255u, w10 = (H1 * W0) & 255u, w11 = (H1 * W1) & 255u;
-  const uint8_t* win = (const uint8_t*)(lds + L::IMG + wave * L::IMG_WAVE) + 2 * x0;
+  const float fh0 = 1.0f - h1, fw0 = 1.0f - w1;
+  char* wbase = lds + L::IMG + wave * L::IMG_WAVE;
   const int* tap = (const int*)(lds + L::TAP);
   const float* cw = (const float*)(lds + L::CW);
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-    // window fill: funnel-shift to 16-byte pieces, mask the border
-    {
+    if constexpr (U8) {   // window fill: funnel-shift to 16-byte pieces, mask the border
       const int sh = o & 3;
       unsigned o4[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) o4[j] = __builtin_amdgcn_alignbyte(tk_d[j + 1], tk_d[j], sh);
       if (pc == 0) o4[0] &= 0xff000000u;
       if (pc == 5) o4[3] &= 0x000000ffu;
-      if (lane < 54)
-        *(i32x4*)(lds + L::IMG + wave * L::IMG_WAVE + rr * 96 + 16 * pc) = (i32x4){(int)o4[0], (int)o4[1], (int)o4[2], (int)o4[3]};
+      if (lane < 54) *(i32x4*)(wbase + rr * 96 + 16 * pc) = (i32x4){(int)o4[0], (int)o4[1], (int)o4[2], (int)o4[3]};
+    } else {
+#pragma unroll
+      for (int j = 0; j < NF; ++j)
+        if (lane + 64 * j < 9 * 96) ((float*)wbase)[lane + 64 * j] = tk_f[j];
     }
     if (b + (int)gridDim.x < a.B) fetch(b + gridDim.x);
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the window is private to this wave
@@ -962,9 +982,16 @@ __global__ __launch_bounds__(512) void ita_tok_stream_kernel(const ItaTokStreamA
 #pragma unroll
     for (int s = 0; s < 13; ++s) {
       const int off = tap[4 * s + kq];
-      const unsigned b256 = (unsigned)win[off] * w00 + (unsigned)win[off + 2] * w01 + (unsigned)win[off + 192] * w10 +
-                            (unsigned)win[off + 194] * w11;
-      tk_pt[s] = (float)b256;
+      if constexpr (U8) {
+        const uint8_t* win = (const uint8_t*)wbase + 2 * x0;
+        const unsigned b256 = (unsigned)win[off] * w00 + (unsigned)win[off + 2] * w01 + (unsigned)win[off + 192] * w10 +
+                              (unsigned)win[off + 194] * w11;
+        tk_pt[s] = (float)b256;
+      } else {
+        const float* win = (const float*)wbase + 2 * x0;
+        const float va = win[off], vb = win[off + 2], vc = win[off + 192], vd = win[off + 194];
+        tk_pt[s] = fh0 * (fw0 * va + w1 * vb) + h1 * (fw0 * vc + w1 * vd);   // ita_oracle_blend_patch's expression
+      }
     }
     f32x4 acc[NCT];
 #pragma unroll
