@@ -294,6 +294,14 @@ def test_fused_tokenizer_path_equals_split_path(torch_cuda, oracle, B):
     for k in ("tokens", "x1", "x2"):
         np.testing.assert_array_equal(tb[k].cpu().numpy()[sel], otp[k], err_msg=k)
     np.testing.assert_allclose(tb["tokens"].cpu().numpy(), ta["tokens"].cpu().numpy(), atol=4e-6, rtol=0)
+    # f32 frames need not be k/255: arbitrary floats (a caller that normalises depth differently, negative values,
+    # values far above 1) take the same blend, conv and LayerNorm expressions as the oracle, bit for bit
+    rs = np.random.RandomState(4000 + B)
+    n = min(B, 5)
+    wild = (rs.standard_normal((n, 60, 90)) * np.exp(rs.uniform(-3, 3, (n, 1, 1)))).astype(np.float32)
+    otw = oracle.tokenizer(wild, fp["tokenizer.conv.weight"].reshape(64, 49), fp["tokenizer.conv.bias"],
+                           fp["tokenizer.norm.weight"], fp["tokenizer.norm.bias"])
+    np.testing.assert_array_equal(eng.tokenizer(cu(wild)).cpu().numpy(), otw)
     eng.close()
 
 
