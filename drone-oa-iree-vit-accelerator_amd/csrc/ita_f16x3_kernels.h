@@ -37,7 +37,7 @@ struct ItaGemmSplitArgs {
   float* out;                             // [nsplit][M][N] raw f32 accumulators
   int M, N, K;                            // K % (64 * nsplit) == 0, N % BN == 0
   int nsplit;
-  int dbg;                                // diagnostic: 1 = stage only (no MFMA), 2 = MFMA only (stage once)
+  int dbg;                                // diagnostic: 1 = stage only (no MFMA), 2 = MFMA only (stage once), 4 no barrier, 8 one buffer, 16/32/64 L2-resident staging
   const _Float16 *wf_hi, *wf_lo;          // the same weights as MFMA A... B fragments, [N / 32][K / 16][lane 64][8] (tiny kernel only)
 };
 
@@ -105,10 +105,12 @@ __global__ __launch_bounds__(64 * WM * WN) void ita_gemm_f16x3_kernel(const ItaG
   auto stage = [&](int buf, int t) {
     char* b = lds + buf * L::BUF;
     const int k0 = kbeg + t * 64;
-    stage_plane<BM, NT>(g.a_hi, g.lda, m0, g.M - 1, k0, b, tid);
-    stage_plane<BM, NT>(g.a_lo, g.lda, m0, g.M - 1, k0, b + L::A_PLANE, tid);
-    stage_plane<BN, NT>(g.w_hi, g.ldw, n0, g.N - 1, k0, b + 2 * L::A_PLANE, tid);
-    stage_plane<BN, NT>(g.w_lo, g.ldw, n0, g.N - 1, k0, b + 2 * L::A_PLANE + L::W_PLANE, tid);
+    // diagnostic masks 16 / 32 / 64: every workgroup stages M tile 0 / N tile 0 / K slice 0 (everything L2-resident)
+    const int m0s = (g.dbg & 16) ? 0 : m0, n0s = (g.dbg & 32) ? 0 : n0, k0s = (g.dbg & 64) ? t * 64 : k0;
+    stage_plane<BM, NT>(g.a_hi, g.lda, m0s, g.M - 1, k0s, b, tid);
+    stage_plane<BM, NT>(g.a_lo, g.lda, m0s, g.M - 1, k0s, b + L::A_PLANE, tid);
+    stage_plane<BN, NT>(g.w_hi, g.ldw, n0s, g.N - 1, k0s, b + 2 * L::A_PLANE, tid);
+    stage_plane<BN, NT>(g.w_lo, g.ldw, n0s, g.N - 1, k0s, b + 2 * L::A_PLANE + L::W_PLANE, tid);
   };
 
   auto compute = [&](int buf) {
