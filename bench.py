@@ -363,8 +363,8 @@ def main():
     NG = 8                                        # time steps per graph replay
     sched = {"on": "graph", "off": "stream"}.get(a.hip_graph, a.schedule)
     if sched == "auto":
-        # measured (tools/pipeline_probe.py, bench --schedule ...): the graph replay and the library's two-thread loop give
-        # the same step at 128-256 frames (43 / 50 us: what the GPU overlaps of front(t+1) and back(t)); below that the
+        # measured (tools/pipeline_probe.py, tools/pipeline3_probe.py, bench --schedule ...): the three-stage graph replay
+        # gives 38 us per step at 128 frames and 48 at 256, the library's two-stage two-thread loop 44 / 50; below that the
         # graph wins (the step is launch-bound and a replay has no launches)
         # (at 512 / 1024 frames the graph replay is also 3 % / 2 % faster than one stream, but the dominant kernel's launch
         #  time for the roofline is then not measured inside the timed region: the default stays "stream" there)
@@ -375,7 +375,7 @@ def main():
         raise SystemExit(f"--schedule {sched} needs u8 frames and --steps that is a multiple of {NG}")
     graph = None
     if sched == "graph":
-        # NG steps per replay on two streams, front(t+1) overlapping back(t): host.PipelinedSteps
+        # NG steps per replay on three streams, encoder(t+2) | folded GEMM(t+1) | LSTM + fc(t): host.PipelinedSteps
         graph = eng.pipelined_steps(B, NG)
         graph.img.copy_(img.unsqueeze(0).expand(NG, -1, -1, -1))
         graph.desvel.copy_(dv.reshape(1, B).expand(NG, -1)); graph.quat.copy_(qt.unsqueeze(0).expand(NG, -1, -1))
@@ -546,7 +546,7 @@ def main():
                        "frames_per_gpu": B, "global_batch": frames_per_step, "parallelism": f"dp{world}",
                        "image_dtype": a.image_dtype, "weights": "seed-0 synthetic QAT (tests/golden)",
                        "schedule": {"stream": "one stream",
-                                    "graph": f"{NG} steps per HIP-graph replay on two streams: front(t+1) overlaps back(t)",
+                                    "graph": f"{NG} steps per HIP-graph replay on three streams: encoder(t+2) | folded GEMM(t+1) | LSTM + fc(t)",
                                     "pipelined": f"{NG} steps per ita_vitlstm_pipelined call: the library's two-stream loop, "
                                                  "front(t+1) overlaps back(t)"}[sched]},
             "roofline": roof, "stages": stages,

@@ -204,8 +204,8 @@ int ensure_workspace(ita_context* c, int B, hipStream_t s = nullptr) {
   HIPCHK(hipMalloc(&c->cat1, sizeof(float) * (size_t)B * 256));
   HIPCHK(hipMalloc(&c->cat2, sizeof(float) * (size_t)B * 256));
   HIPCHK(hipMalloc(&c->gates, sizeof(float) * (size_t)B * 512));
-  HIPCHK(hipMalloc(&c->x2_hi, 2 * (size_t)B * c->ldfold));
-  HIPCHK(hipMalloc(&c->x2_lo, 2 * (size_t)B * c->ldfold));
+  HIPCHK(hipMalloc(&c->x2_hi, 2 * 2 * (size_t)B * c->ldfold));   // two sets of planes: ita_vitlstm_encode / _fold ping-pong
+  HIPCHK(hipMalloc(&c->x2_lo, 2 * 2 * (size_t)B * c->ldfold));
   HIPCHK(hipMalloc(&c->c1_hi, 2 * (size_t)((B + 31) / 32 * 32) * 256));   // fragment order, whole 32-frame tiles
   HIPCHK(hipMalloc(&c->c1_lo, 2 * (size_t)((B + 31) / 32 * 32) * 256));   // fragment order, whole 32-frame tiles
   HIPCHK(hipMalloc(&c->c2_hi, 2 * (size_t)((B + 31) / 32 * 32) * 256));   // fragment order, whole 32-frame tiles
@@ -1294,16 +1294,20 @@ int ita_vitlstm_tail(ita_handle h, const float* x2, const float* desvel, const f
 }
 
 // ---- two-stage form for software pipelining across time steps -------------------------------------
+// parts: 1 = tokenizer + encoder into the x2 planes `xbuf`, 2 = folded GEMM from planes `xbuf` into partial buffer `buf`
 static int front_impl(ita_handle h, const void* image, int image_dtype, int batch, int buf, void* stream,
-                      void* encoder_done_event) {
+                      void* encoder_done_event, int xbuf = 0, int parts = 3) {
   int rc = check(h, batch);
   if (rc) return rc;
-  if (!image || buf < 0 || buf >= ITA_PART_BUFFERS) return fail(ITA_ERR_INVALID_ARG, "null image or buf not in [0, ITA_PART_BUFFERS)");
-  if (image_dtype != ITA_IMAGE_F32 && image_dtype != ITA_IMAGE_U8) return fail(ITA_ERR_INVALID_ARG, "bad image dtype");
+  if (((parts & 1) && !image) || buf < 0 || buf >= ITA_PART_BUFFERS || xbuf < 0 || xbuf > 1)
+    return fail(ITA_ERR_INVALID_ARG, "null image, buf not in [0, ITA_PART_BUFFERS) or plane set not 0 / 1");
+  if ((parts & 1) && image_dtype != ITA_IMAGE_F32 && image_dtype != ITA_IMAGE_U8) return fail(ITA_ERR_INVALID_ARG, "bad image dtype");
   if (!(h->tail_mode == 1 && h->folded)) return fail(ITA_ERR_UNSUPPORTED, "front/back form needs tail mode 1 and a full ITAViTLSTM blob");
   if ((rc = ensure_workspace(h, batch, (hipStream_t)stream))) return rc;
-  h->front_cap[buf] = h->cap;
+  if (parts & 2) h->front_cap[buf] = h->cap;
   hipStream_t s = (hipStream_t)stream;
+  _Float16* const xh = h->x2_hi + (size_t)xbuf * h->cap * h->ldfold;
+  _Float16* const xl = h->x2_lo + (size_t)xbuf * h->cap * h->ldfold;
   // sampled single-stage profiling (ita_profile_begin_sampled with only_stage 0, 1 or 3) also works here
   const int L2 = 2 * h->hdr.num_layers, per = 5 + L2;
   hipEvent_t* ev = nullptr;
@@ -1316,22 +1320,27 @@ static int front_impl(ita_handle h, const void* image, int image_dtype, int batc
     }
     return ITA_OK;
   };
-  if ((rc = mark(0, false))) return rc;
-  const bool fused_tok = fuse_tokenizer(h, image_dtype);
-  if (!fused_tok && (rc = launch_tokenizer(h, image, image_dtype, h->bufA, batch, s))) return rc;
-  if ((rc = mark(0, true)) || (rc = mark(1, false))) return rc;
-  for (int l = 0; l < h->hdr.num_layers; ++l) {
-    const bool last = l == h->hdr.num_layers - 1;
-    if ((rc = launch_encoder(h, l, h->bufA, last ? nullptr : h->bufA, last ? h->x2_hi : nullptr, last ? h->x2_lo : nullptr,
-                             nullptr, batch, s, nullptr, nullptr, nullptr, nullptr, (fused_tok && l == 0) ? image : nullptr,
-                             nullptr))) return rc;
+  if (parts & 1) {
+    if ((rc = mark(0, false))) return rc;
+    const bool fused_tok = fuse_tokenizer(h, image_dtype);
+    if (!fused_tok && (rc = launch_tokenizer(h, image, image_dtype, h->bufA, batch, s))) return rc;
+    if ((rc = mark(0, true)) || (rc = mark(1, false))) return rc;
+    for (int l = 0; l < h->hdr.num_layers; ++l) {
+      const bool last = l == h->hdr.num_layers - 1;
+      if ((rc = launch_encoder(h, l, h->bufA, last ? nullptr : h->bufA, last ? xh : nullptr, last ? xl : nullptr,
+                               nullptr, batch, s, nullptr, nullptr, nullptr, nullptr, (fused_tok && l == 0) ? image : nullptr,
+                               nullptr))) return rc;
+    }
+    if ((rc = mark(1, true))) return rc;
+    if (encoder_done_event) HIPCHK(hipEventRecord((hipEvent_t)encoder_done_event, s));
   }
-  if ((rc = mark(1, true)) || (rc = mark(3, false))) return rc;
-  if (encoder_done_event) HIPCHK(hipEventRecord((hipEvent_t)encoder_done_event, s));
-  float* part = h->part + (size_t)buf * NSPLIT * h->cap * 512;
-  if ((rc = launch_gemm_split<128, 128, 2, 4>(h->x2_hi, h->x2_lo, h->ldfold, h->fold_hi, h->fold_lo, h->ldfold, part, batch, 512,
-                                              h->kfold, NSPLIT, s, h->foldf_hi, h->foldf_lo))) return rc;
-  if ((rc = mark(3, true))) return rc;
+  if (parts & 2) {
+    if ((rc = mark(3, false))) return rc;
+    float* part = h->part + (size_t)buf * NSPLIT * h->cap * 512;
+    if ((rc = launch_gemm_split<128, 128, 2, 4>(xh, xl, h->ldfold, h->fold_hi, h->fold_lo, h->ldfold, part, batch, 512,
+                                                h->kfold, NSPLIT, s, h->foldf_hi, h->foldf_lo))) return rc;
+    if ((rc = mark(3, true))) return rc;
+  }
   if (ev && (h->prof_stage == 0 || h->prof_stage == 1 || h->prof_stage == 3)) ++h->prof_n;
   return ITA_OK;
 }
@@ -1343,6 +1352,14 @@ int ita_vitlstm_front(ita_handle h, const void* image, int image_dtype, int batc
 int ita_vitlstm_front_ev(ita_handle h, const void* image, int image_dtype, int batch, int buf, void* stream,
                          void* encoder_done_event) {
   return front_impl(h, image, image_dtype, batch, buf, stream, encoder_done_event);
+}
+
+int ita_vitlstm_encode(ita_handle h, const void* image, int image_dtype, int batch, int plane_set, void* stream) {
+  return front_impl(h, image, image_dtype, batch, 0, stream, nullptr, plane_set, 1);
+}
+
+int ita_vitlstm_fold(ita_handle h, int batch, int plane_set, int buf, void* stream) {
+  return front_impl(h, nullptr, ITA_IMAGE_U8, batch, buf, stream, nullptr, plane_set, 2);
 }
 
 int ita_vitlstm_back(ita_handle h, const float* desvel, const float* quat, const float* h_in, const float* c_in, float* vel,

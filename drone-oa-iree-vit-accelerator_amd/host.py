@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = (
     "ita_profile_begin", "ita_profile_begin_sampled", "ita_profile_end", "ita_set_tail_mode", "ita_debug_encoder_stamps",
     "ita_fusion_tail_load", "ita_fusion_tail_large",
     "ita_wire_unpack_packet", "ita_wire_postprocess", "ita_vitlstm_forward_slots", "ita_vitlstm_front",
-    "ita_vitlstm_back", "ita_vitlstm_pipelined", "ita_vitlstm_front_ev", "ita_vitlstm_tail", "ita_debug_softmax_rows",
+    "ita_vitlstm_back", "ita_vitlstm_pipelined", "ita_vitlstm_front_ev", "ita_vitlstm_encode", "ita_vitlstm_fold", "ita_vitlstm_tail", "ita_debug_softmax_rows",
     "ITASelfAttention_workgroup", "ITASelfAttention_workgroup_expanded", "ITAFeedForward_workgroup",
 )
 
@@ -115,6 +115,8 @@ def lib():
         L.ita_vitlstm_forward_slots.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, i, vp, i, vp]
         L.ita_vitlstm_front.argtypes = [vp, vp, i, i, i, vp]
         L.ita_vitlstm_front_ev.argtypes = [vp, vp, i, i, i, vp, vp]
+        L.ita_vitlstm_encode.argtypes = [vp, vp, i, i, i, vp]
+        L.ita_vitlstm_fold.argtypes = [vp, i, i, i, vp]
         L.ita_vitlstm_back.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp]
         L.ita_vitlstm_pipelined.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, i, i, vp, vp]
         L.ita_mha_q8.argtypes = [vp, i, vp, vp, i, vp]
@@ -388,6 +390,18 @@ class Engine:
         _chk(lib().ita_vitlstm_front_ev(self._h, img.data_ptr(), dt, img.shape[0], buf, sp, ev))
         return img.shape[0]
 
+    def encode(self, img, plane_set: int, stream=None):
+        """tokenizer + encoder of a time step into plane set 0 / 1 (ita_vitlstm_encode)"""
+        img, dt = self._image(img)
+        sp = _stream_ptr(self.device) if stream is None else C.c_void_p(stream.cuda_stream)
+        _chk(lib().ita_vitlstm_encode(self._h, img.data_ptr(), dt, img.shape[0], plane_set, sp))
+        return img.shape[0]
+
+    def fold(self, batch: int, plane_set: int, buf: int, stream=None):
+        """folded GEMM of a time step: plane set -> partial buffer `buf` (ita_vitlstm_fold)"""
+        sp = _stream_ptr(self.device) if stream is None else C.c_void_p(stream.cuda_stream)
+        _chk(lib().ita_vitlstm_fold(self._h, batch, plane_set, buf, sp))
+
     def pipelined(self, imgs, desvels, quats, state, vels, stream_front, stream_back):
         """n time steps pipelined on two torch streams by the library (ita_vitlstm_pipelined): imgs / desvels / quats /
         vels are sequences of per-step tensors (or a tensor with a leading step axis), state = (h, c) updated in place"""
@@ -426,9 +440,10 @@ class Engine:
         _chk(lib().ita_reserve(self._h, batch))
         return GraphedStep(self, batch)
 
-    def pipelined_steps(self, batch: int, n_steps: int = 8) -> "PipelinedSteps":
-        """n_steps time steps per HIP-graph replay, front(t+1) overlapping back(t) (see PipelinedSteps)"""
-        return PipelinedSteps(self, batch, n_steps)
+    def pipelined_steps(self, batch: int, n_steps: int = 8, stages: int = 3) -> "PipelinedSteps":
+        """n_steps time steps per HIP-graph replay: encoder(t+2) | folded GEMM(t+1) | LSTM + fc(t) on three streams
+        (stages = 2: front(t+1) | back(t) on two); see PipelinedSteps"""
+        return PipelinedSteps(self, batch, n_steps, stages)
 
     # ---- drop-in symbols (host buffers) --------------------------------------------------
     def bind_dispatch(self, layer: int = 0, dtype: int = DISPATCH_F16):
@@ -478,7 +493,12 @@ PART_BUFFERS = 8    # ITA_PART_BUFFERS of include/ita_mi355x.h: partial-sum buff
 
 
 class PipelinedSteps:
-    """`n_steps` consecutive time steps captured in ONE HIP graph on two streams: the image-only front of step t+1
+    """`n_steps` consecutive time steps captured in ONE HIP graph.  stages = 3 (default), three streams: the encoder of step
+    t+2 (ita_vitlstm_encode), the folded GEMM of step t+1 (ita_vitlstm_fold) and the LSTM layers + fc of step t
+    (ita_vitlstm_back) run side by side, with two sets of encoder-output planes and three partial-sum buffers; measured per
+    step (tools/pipeline3_probe.py): 1 frame 31.7 us, 64 frames 36.1, 128 frames 38.2, 256 frames 47.7 -- against 34.0 / 39.7 /
+    43.0 / 47.6 for stages = 2, which is the rest of this description.
+    stages = 2, two streams: the image-only front of step t+1
     (tokenizer, encoder, folded GEMM: ita_vitlstm_front) runs while the recurrent back of step t (LSTM layers, fc:
     ita_vitlstm_back) is still in flight.  The recurrence is respected -- back(t) follows back(t-1) on its stream and
     front(t) -- and so is the reuse of the partial-sum buffers (front(t) waits for back(t - PART_BUFFERS); with n_steps <=
@@ -489,10 +509,10 @@ class PipelinedSteps:
     Static buffers: `img` (n,B,60,90) u8, `desvel` (n,B), `quat` (n,B,4) in; `vel` (n,B,3) out; `h`, `c` (3,B,128) carried
     in place from step to step and from replay to replay (zero them to start new streams)."""
 
-    def __init__(self, engine: "Engine", batch: int, n_steps: int = 8):
+    def __init__(self, engine: "Engine", batch: int, n_steps: int = 8, stages: int = 3):
         torch = _torch()
         dev = torch.device("cuda", engine.device)
-        self.engine, self.B, self.n = engine, batch, n_steps
+        self.engine, self.B, self.n, self.stages = engine, batch, n_steps, stages
         _chk(lib().ita_reserve(engine._h, batch))
         self.img = torch.zeros((n_steps, batch, 60, 90), dtype=torch.uint8, device=dev)
         self.desvel = torch.zeros((n_steps, batch), dtype=torch.float32, device=dev)
@@ -519,6 +539,41 @@ class PipelinedSteps:
         # overlaps the two branches of the replayed graph (41.9 us per 128-frame step for 32.6 us of front and 17.3 us of
         # back); without that edge (8 buffers) it runs them one after the other (52.5 us; tools/pipeline_probe.py).
         nb = 2
+        if stages == 3:
+            # encoder(i+2) | folded GEMM(i+1) | LSTM + fc(i): three branches, two plane sets, two partial buffers
+            s_fold = torch.cuda.Stream(device=dev)
+            ev_enc = [torch.cuda.Event() for _ in range(n_steps)]
+            ev_planes = [torch.cuda.Event() for _ in range(n_steps)]   # (one event per waiter)
+            ev_fork = torch.cuda.Event()
+            with torch.cuda.graph(self.graph, stream=s_front):
+                # both side streams fork from the ORIGIN stream (a stream that joins the capture through an event of
+                # another forked stream crashes hipStreamEndCapture on ROCm 7.0)
+                ev_fork.record(s_front)
+                s_fold.wait_event(ev_fork)
+                s_back.wait_event(ev_fork)
+                for i in range(n_steps):
+                    if i >= 2:
+                        s_front.wait_event(ev_planes[i - 2])       # encode(i) overwrites the planes fold(i-2) read
+                    if i >= 3:
+                        # fold(i) overwrites the partials back(i-3) read (three partial buffers).  The edge goes through
+                        # the origin stream -- fold(i) follows encode(i) anyway, and back(i-3) is two steps behind the
+                        # encoder in steady state -- because a forked stream that waits for an event downstream of its
+                        # own earlier work crashes hipStreamEndCapture on ROCm 7.0
+                        s_front.wait_event(ev_back[i - 3])
+                    engine.encode(self.img[i], i & 1, stream=s_front)
+                    ev_enc[i].record(s_front)
+                    s_fold.wait_event(ev_enc[i])
+                    engine.fold(batch, i & 1, i % 3, stream=s_fold)
+                    ev_front[i].record(s_fold)
+                    ev_planes[i].record(s_fold)
+                    s_back.wait_event(ev_front[i])
+                    engine.back(self.desvel[i], self.quat[i], (self.h, self.c), (self.vel[i], self.h, self.c), i % 3, stream=s_back)
+                    ev_back[i].record(s_back)
+                s_front.wait_stream(s_fold)                         # join
+                s_front.wait_stream(s_back)
+            self.h.zero_()
+            self.c.zero_()
+            return
         with torch.cuda.graph(self.graph, stream=s_front):
             for i in range(n_steps):
                 if i >= nb:

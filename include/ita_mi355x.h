@@ -150,6 +150,15 @@ int ita_vitlstm_front(ita_handle h, const void* image_dev, int image_dtype, int 
  * puts the LSTM kernels of step t next to the GEMM of step t+1, which leaves room for them. */
 int ita_vitlstm_front_ev(ita_handle h, const void* image_dev, int image_dtype, int batch, int buf, void* stream,
                          void* encoder_done_event);
+/* The front cut once more, for a THREE-stage pipeline: encoder(t+2) | folded GEMM(t+1) | LSTM + fc(t) on three streams.
+ * ita_vitlstm_encode writes the encoder output planes into plane set `plane_set` (0 or 1), ita_vitlstm_fold multiplies
+ * that set into partial buffer `buf`; encode + fold on one stream with plane_set 0 equals ita_vitlstm_front.  The caller
+ * orders them with events: fold(t) after encode(t); encode(t') after fold(t) when it reuses t's plane set; back(t) after
+ * fold(t); fold(t') after back(t) when it reuses t's partial buffer.  Measured from one HIP graph of 8 steps
+ * (host.PipelinedSteps): 128 frames per step 38.2 us against 43.0 us for the two-stage form, 64 frames 36.1 / 39.7, one frame
+ * 31.7 / 34.0. */
+int ita_vitlstm_encode(ita_handle h, const void* image_dev, int image_dtype, int batch, int plane_set, void* stream);
+int ita_vitlstm_fold(ita_handle h, int batch, int plane_set, int buf, void* stream);
 int ita_vitlstm_back(ita_handle h, const float* additional_data_dev, const float* quat_data_dev,
                      const float* hidden_in_h_dev, const float* hidden_in_c_dev, float* output_dev,
                      float* hidden_out_h_dev, float* hidden_out_c_dev, int batch, int buf, void* stream);

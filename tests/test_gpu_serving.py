@@ -154,9 +154,11 @@ def test_graphed_step_equals_eager_forward():
     eng.close()
 
 
+@pytest.mark.parametrize("stages", [2, 3])
 @pytest.mark.parametrize("B", [3, 130])
-def test_pipelined_graph_steps_equal_sequential_forward(B):
-    """host.PipelinedSteps: 8 time steps per HIP-graph replay with front(t+1) overlapping back(t) on a second stream must
+def test_pipelined_graph_steps_equal_sequential_forward(B, stages):
+    """host.PipelinedSteps: 8 time steps per HIP-graph replay with front(t+1) overlapping back(t) on a second stream -- or,
+    stages = 3, encoder(t+2) | folded GEMM(t+1) | LSTM(t) on three (ita_vitlstm_encode / _fold, two plane sets) -- must
     give, step by step and across two replays (state carried), exactly the velocities and the state of 16 sequential
     ita_vitlstm_forward calls."""
     import torch
@@ -164,7 +166,7 @@ def test_pipelined_graph_steps_equal_sequential_forward(B):
     eng = host.Engine(params.blob_from_record(fx, synth.float_params(0, E=64), E=64), device=0)
     n = 8
     frs = [synth.frames(500 + t, B) for t in range(2 * n)]
-    ps = eng.pipelined_steps(B, n)
+    ps = eng.pipelined_steps(B, n, stages)
     got = []
     for rep in range(2):
         for t in range(n):
