@@ -62,3 +62,22 @@ print(f"{B} frames per step; us per time step from {N}-step HIP graphs")
 for k, v in res.items():
     print(f"  {k:12s} {v:7.2f}")
 eng.close()
+
+# ---- the same library loop on streams with disjoint CU masks (front: every even CU bit, back: every odd one)
+if os.environ.get("ITA_PROBE_CUMASK"):
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    def masked_stream(word):
+        st = C.c_void_p()
+        mask = (C.c_uint32 * 8)(*([word] * 8))
+        rc = hip.hipExtStreamCreateWithCUMask(C.byref(st), 8, mask)
+        assert rc == 0, rc
+        return torch.cuda.ExternalStream(st.value)
+    eng2 = host.Engine(params.blob_from_record(d, synth.float_params(0), E=64), device=0, reserve=B)
+    for name, (wa, wb) in {"even | odd": (0x55555555, 0xAAAAAAAA), "lo16 | hi16 of 32": (0x0000FFFF, 0xFFFF0000),
+                           "all | all (ext streams)": (0xFFFFFFFF, 0xFFFFFFFF)}.items():
+        mf, mb = masked_stream(wa), masked_stream(wb)
+        with torch.cuda.stream(mf):
+            t = timeit(lambda: eng2.pipelined(*args40, mf, mb), reps=20) * N / M
+        print(f"  C++ loop x40, CU masks {name:24s} {t:7.2f}")
+    eng2.close()
