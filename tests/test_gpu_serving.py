@@ -189,6 +189,37 @@ def test_pipelined_graph_steps_equal_sequential_forward(B, stages):
     eng.close(); eng2.close()
 
 
+def test_three_stage_graph_on_the_two_layer_e128_graph():
+    """The three-stage pipeline on the second graph family (E = 128, two encoder layers, no fusion tail): there the encode
+    stage runs a tokenizer launch and two layer launches through the shared token buffer while the fold stage of the previous
+    step reads the other plane set.  Must equal sequential ita_vitlstm_forward calls bit for bit."""
+    import glob
+    import torch
+    path = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "vit2l_*.npz")))[0]
+    d = params.load_fixture(path)
+    nl = int(d["meta.num_layers"])
+    fp = synth.float_params(int(d["meta.seed"]), E=128, num_layers=nl, tail=False)
+    blob = params.blob_from_record(d, fp, E=128, num_layers=nl)
+    B, n = 37, 6
+    eng, eng2 = host.Engine(blob, device=0), host.Engine(blob, device=0)
+    ps = eng.pipelined_steps(B, n, 3)
+    frs = [synth.frames(700 + t, B) for t in range(n)]
+    for t, f in enumerate(frs):
+        ps.img[t].copy_(torch.from_numpy(f["img_u8"]))
+        ps.desvel[t].copy_(torch.from_numpy(f["desvel"]).reshape(B))
+        ps.quat[t].copy_(torch.from_numpy(f["quat"]))
+    got = ps().clone()
+    torch.cuda.synchronize()
+    st = None
+    for t, f in enumerate(frs):
+        v, st = eng2.forward(torch.from_numpy(f["img_u8"]).cuda(), torch.from_numpy(f["desvel"]).cuda(),
+                             torch.from_numpy(f["quat"]).cuda(), st)
+        assert torch.equal(got[t], v), f"step {t}"
+    assert torch.equal(ps.h, st[0]) and torch.equal(ps.c, st[1])
+    del ps
+    eng.close(); eng2.close()
+
+
 @pytest.mark.parametrize("B,n", [(3, 5), (130, 12)])
 def test_library_pipelined_steps_equal_sequential_forward(B, n):
     """ita_vitlstm_pipelined (the library's own two-stream loop: front(t+1) next to back(t), ping-pong state, event
