@@ -540,7 +540,7 @@ class PipelinedSteps:
         # back); without that edge (8 buffers) it runs them one after the other (52.5 us; tools/pipeline_probe.py).
         nb = 2
         if stages == 3:
-            # encoder(i+2) | folded GEMM(i+1) | LSTM + fc(i): three branches, two plane sets, two partial buffers
+            # encoder(i+2) | folded GEMM(i+1) | LSTM + fc(i): three branches, two plane sets, three partial buffers
             s_fold = torch.cuda.Stream(device=dev)
             ev_enc = [torch.cuda.Event() for _ in range(n_steps)]
             ev_planes = [torch.cuda.Event() for _ in range(n_steps)]   # (one event per waiter)
