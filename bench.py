@@ -20,7 +20,8 @@ Prints ONE JSON line (rank 0).  Extra objects:
                 scalar int8 oracle (oracle/ita_oracle.c), one process per core and one core alone
   configs       c2: BASELINE config 2 (int8 MHA block alone: B = 1 latency, 1024-frame int8 MFMA fraction);
                 c5: BASELINE config 5 (fusion tail on a 64x128 token grid: MFMA and HBM fractions), same run (N = 1 only);
-                vit2l: the second graph family (E = 128, two layers, no fusion tail), whole forward at 1024 frames
+                vit2l: the second graph family (E = 128, two layers, no fusion tail), whole forward at 1024 frames;
+                b1 / b128 / b256: step time of the whole forward at 1, 128, 256 frames per GPU (config 3; config 4 cut over 8 GPUs)
 --schedule selects one stream / the library's two-stream pipeline / its HIP-graph form (default: graph up to 256 frames per GPU).
 --global-batch G gives the strong-scaling form of config 4 (G frames per step cut over the GPUs, "scaling": "strong").
 """
@@ -287,6 +288,48 @@ def bench_vit2l(frames=1024, iters=50):
             "timing": f"wall clock over {iters} forwards, one stream"}
 
 
+def bench_small(blob, batches=(1, 128, 256), replays=60):
+    """The small-batch / strong-scaling regime of BASELINE config 4 (1024 frames cut over 8 GPUs = 128 per GPU; config 3 =
+    one frame): step time of the whole forward at 1, 128 and 256 frames per GPU with the schedule bench.py itself picks
+    there (8 steps per HIP-graph replay on three streams), beside the same step on one stream (six launches per step)."""
+    import torch
+    from drone_oa_iree_vit_accelerator_amd import host, synth
+    out = {}
+    for B in batches:
+        eng = host.Engine(blob, device=torch.cuda.current_device(), reserve=B)
+        fr = synth.frames(4321, B)
+        img, dv, qt = (torch.from_numpy(fr[k]).cuda() for k in ("img_u8", "desvel", "quat"))
+        NG = 8
+        g = eng.pipelined_steps(B, NG)
+        g.img.copy_(img.unsqueeze(0).expand(NG, -1, -1, -1))
+        g.desvel.copy_(dv.reshape(1, B).expand(NG, -1)); g.quat.copy_(qt.unsqueeze(0).expand(NG, -1, -1))
+        for _ in range(40):
+            g()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(replays):
+            g()
+        torch.cuda.synchronize()
+        ms_graph = (time.perf_counter() - t0) / (replays * NG) * 1e3
+        del g
+        st = [(torch.zeros((3, B, 128), device="cuda"), torch.zeros((3, B, 128), device="cuda")) for _ in range(2)]
+        vel = torch.empty((B, 3), device="cuda")
+        for i in range(40):
+            eng.forward(img, dv, qt, st[i & 1], out=(vel, *st[(i + 1) & 1]))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(replays * NG):
+            eng.forward(img, dv, qt, st[i & 1], out=(vel, *st[(i + 1) & 1]))
+        torch.cuda.synchronize()
+        ms_stream = (time.perf_counter() - t0) / (replays * NG) * 1e3
+        eng.close()
+        out[f"b{B}"] = {"frames_per_gpu": B, "ms_per_step": round(ms_graph, 5), "frames_per_s": round(B / ms_graph * 1e3, 1),
+                        "schedule": f"{NG} steps per HIP-graph replay on three streams: encoder(t+2) | folded GEMM(t+1) | LSTM + fc(t)",
+                        "ms_per_step_one_stream": round(ms_stream, 5),
+                        "timing": f"wall clock over {replays} replays ({replays * NG} steps) after 40 warm-up replays"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -313,6 +356,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE config 2 / config 5 legs (configs.c2, configs.c5)")
+    ap.add_argument("--gather-every", type=int, choices=[1, 8], default=1,
+                    help="N > 1: steps per velocity all-gather.  1 (default): one asynchronous all-gather per time step, the "
+                         "exchange BASELINE.json's north_star names -- a consumer sees a step's velocities one step later.  "
+                         "8: the velocities of 8 steps travel in one all-gather (fewer collective kernels beside the encoder's "
+                         "persistent workgroups, but a consumer sees them up to 16 steps late).  The graph / pipelined schedules "
+                         "replay 8 steps per host call and therefore always gather once per replay; the line says which was timed")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' only to "
                     "rehearse the N>1 code path with several ranks on one GPU (set ITA_FORCE_DEVICE=0)")
     a = ap.parse_args()
@@ -391,10 +440,15 @@ def main():
             def __call__(self):
                 eng.pipelined(*self.args, self.sf, self.sb)     # joins on its front stream: run under torch.cuda.stream(sf)
         graph = LibPipeline()
-    batched_gather = graph is None and not strong
+    batched_gather = graph is None and a.gather_every == NG
     velring = torch.empty((2, NG, B, 3), device=dev) if batched_gather else None
-    if graph is not None or batched_gather:
-        gather = itadist.VelocityGather(NG * B, world, dev)    # one all-gather per NG steps: their velocities
+    gather_every = NG if (graph is not None or batched_gather) else 1
+    if gather_every == NG:
+        # one all-gather per NG steps: rank r sends NG x (its shard) rows; uneven shards (strong scaling) are padded to the
+        # longest.  A graph replay / library call writes ONE velocity buffer again and again, so its rows are staged into
+        # the gather's own ping-pong send buffers (stream-ordered copy) before the collective starts.
+        shard = [hi_ - lo_ for lo_, hi_ in (itadist.shard_range(total, r, world) for r in range(world))] if strong else [B] * world
+        gather = itadist.VelocityGather(NG * B, world, dev, sizes=[NG * sz for sz in shard], stage=graph is not None)
     torch.cuda.synchronize()
 
     def step(i):
@@ -404,17 +458,15 @@ def main():
                 # (the library pipeline's calls and their all-gathers stay on its front stream: no join with another
                 #  stream between calls, the next call's fronts queue up behind this call's last back)
                 with torch.cuda.stream(graph.sf) if sched == "pipelined" else contextlib.nullcontext():
-                    if world > 1:
-                        gather.ready()
-                    graph()
+                    graph()      # (its one velocity buffer is free: gather.start staged the previous replay's rows)
                     if world > 1:
                         gather.start(graph.vel.reshape(NG * B, 3))
             return
         src, dst = state[i & 1], state[(i + 1) & 1]
         if batched_gather:
-            # weak scaling, equal shards: the velocities of NG steps go out in ONE all-gather (96 KiB instead of eight times
-            # 12 KiB).  The encoder's persistent workgroups need every CU; a collective's kernel that holds one for 10-20 us
-            # delays the whole launch by that much, so the fewer collectives share the GPU with it the better.
+            # --gather-every 8: the velocities of NG steps go out in ONE all-gather (96 KiB instead of eight times 12 KiB).
+            # The encoder's persistent workgroups need every CU; a collective's kernel that holds one for 10-20 us delays
+            # the whole launch by that much, so the fewer collectives share the GPU with it the better.
             half, k = (i // NG) & 1, i % NG
             if world > 1 and k == 0:
                 gather.ready()      # the all-gather of two groups ago read this half of the velocity ring
@@ -545,6 +597,10 @@ def main():
                                    ", LSTM state carried, velocity all-gather",
                        "frames_per_gpu": B, "global_batch": frames_per_step, "parallelism": f"dp{world}",
                        "image_dtype": a.image_dtype, "weights": "seed-0 synthetic QAT (tests/golden)",
+                       "gather_every": gather_every,
+                       "gather": ("none (one GPU)" if world == 1 else
+                                  f"asynchronous all-gather of the (frames, 3) velocities every {gather_every} step(s), "
+                                  f"double-buffered, backend {a.backend}"),
                        "schedule": {"stream": "one stream",
                                     "graph": f"{NG} steps per HIP-graph replay on three streams: encoder(t+2) | folded GEMM(t+1) | LSTM + fc(t)",
                                     "pipelined": f"{NG} steps per ita_vitlstm_pipelined call: the library's two-stream loop, "
@@ -584,7 +640,7 @@ def main():
             # the other single-GPU configurations of BASELINE.json, measured in this same run
             del graph
             eng.close()
-            out["configs"] = {"c2": bench_c2(), "c5": bench_c5()}
+            out["configs"] = {"c2": bench_c2(), "c5": bench_c5(), **bench_small(blob)}
             v2 = bench_vit2l()
             if v2:
                 out["configs"]["vit2l"] = v2

@@ -458,14 +458,14 @@ int launch_encoder(ita_context* c, int layer, const float* x, float* y, _Float16
     return launch_stream(c, layer, 0, false, io, B, s);
   }
   if (img) return fail(ITA_ERR_INVALID_ARG, "launch_encoder: frames need the tokenizer image");
-  int rc = ensure_workspace(c, B);
+  // (everything that can refuse is checked before the first launch: no partial work is left behind an error)
+  if (h0_dst && slots) return fail(ITA_ERR_UNSUPPORTED, "slot-indexed state needs the stream kernel (this blob's accumulator range rules it out)");
+  int rc = ensure_workspace(c, B, s);
   if (rc) return rc;
   if ((rc = launch_mha(c, layer, x, c->bufB, B, true, nullptr, s))) return rc;
   if (x1_tap) HIPCHK(hipMemcpyAsync(x1_tap, c->bufB, sizeof(float) * (size_t)B * 128 * c->hdr.E, hipMemcpyDeviceToDevice, s));
-  if (h0_dst) {   // the side copy the stream kernel makes for the LSTM (rows by slot when slots are given: not on this path)
-    if (slots) return fail(ITA_ERR_UNSUPPORTED, "slot-indexed state needs the stream kernel");
+  if (h0_dst)   // the side copy the stream kernel makes for the LSTM
     HIPCHK(hipMemcpyAsync(h0_dst, h0_src, sizeof(float) * (size_t)B * 128, hipMemcpyDeviceToDevice, s));
-  }
   return launch_ffn(c, layer, c->bufB, y, B, true, nullptr, s, y_hi, y_lo);
 }
 
@@ -529,19 +529,20 @@ int launch_gemm(const float* A, int lda, const float* W, int ldw, const float* b
 
 template <int NT, int WAVES, int TPS>
 int launch_tail_big_w(const ItaTailBigArgs& a, hipStream_t s) {
-  // the attribute is per DEVICE: one flag per ordinal (a process-wide flag left the second GPU's context without it)
+  // the attribute is per DEVICE: one bit per ordinal (a process-wide flag left the second GPU's context without it).
+  // Lock-free on the launch path: the mutex is only taken by the first launch on a device.
   static std::mutex mu;
-  static std::vector<char> attr_set;
+  static std::atomic<uint64_t> attr_set{0};
   auto kern = ita_tail_big_kernel<NT, WAVES, TPS>;
   constexpr int lds_bytes = ItaTailBigLds<NT, WAVES, TPS>::TOTAL;
   {
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> g(mu);
-    if ((int)attr_set.size() <= dev) attr_set.resize(dev + 1, 0);
-    if (!attr_set[dev]) {
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(attr_set.load(std::memory_order_acquire) & bit)) {
+      std::lock_guard<std::mutex> g(mu);
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-      attr_set[dev] = 1;
+      attr_set.fetch_or(bit, std::memory_order_release);
     }
   }
   hipLaunchKernelGGL(kern, dim3(2 * a.TW / 32, 2 * a.TH / (2 * WAVES), a.B), dim3(64 * WAVES), lds_bytes, s, a);
@@ -1187,6 +1188,11 @@ static int forward_impl(ita_handle h, const void* image, int image_dtype, const 
 #define MARK() do { if (ev && (h->prof_stage < 0 || evi == m_lo || evi == m_hi)) HIPCHK(hipEventRecord(ev[evi], s)); ++evi; } while (0)
   MARK();
   const bool fused_tok = !x2_in && fuse_tokenizer(h, image_dtype);
+  if (slots && !x2_in) {   // refuse before the first launch: the slot-indexed side copy of h lives in the stream kernel
+    const Layer& LL = h->layers.back();
+    if (!((fused_tok && h->hdr.num_layers == 1) ? LL.simg_tok : LL.simg_enc))
+      return fail(ITA_ERR_UNSUPPORTED, "slot-indexed state needs the stream kernel (this blob's accumulator range rules it out)");
+  }
   if (x2_in) {
     HIPCHK(hipMemcpyAsync(h->bufA, x2_in, tokb, hipMemcpyDeviceToDevice, s));
     if (fast) {
@@ -1289,7 +1295,7 @@ int ita_vitlstm_forward(ita_handle h, const void* image, int image_dtype, const 
 int ita_vitlstm_tail(ita_handle h, const float* x2, const float* desvel, const float* quat, const float* h_in,
                      const float* c_in, float* vel, float* h_out, float* c_out, int batch, void* stream) {
   if (!x2) return fail(ITA_ERR_INVALID_ARG, "null pointer");
-  if (h && h->loaded && h->hdr.E != 64) return fail(ITA_ERR_UNSUPPORTED, "the fusion tail is built for E = 64 (ITAViTLSTM)");
+  // (both graph families: with the fusion tail E = 64 -- forward_impl checks --, without it the decoder reads x2 itself)
   return forward_impl(h, nullptr, ITA_IMAGE_F32, desvel, quat, h_in, c_in, vel, h_out, c_out, batch, nullptr, stream, nullptr, 0, x2);
 }
 
@@ -1409,6 +1415,8 @@ int ita_vitlstm_pipelined(ita_handle h, const void* const* image, int image_dtyp
   if (!image || !desvel || !quat || !state_h || !state_c || !vel || n_steps <= 0 || !stream_front || !stream_back ||
       stream_front == stream_back)
     return fail(ITA_ERR_INVALID_ARG, "null argument, n_steps <= 0, or the two streams are not two distinct non-default streams");
+  if (h->prof)   // two host threads would write the one profiling state of this handle
+    return fail(ITA_ERR_INVALID_ARG, "ita_vitlstm_pipelined cannot run between ita_profile_begin and ita_profile_end");
   if ((rc = ensure_workspace(h, batch, (hipStream_t)stream_front))) return rc;
   hipStream_t sf = (hipStream_t)stream_front, sb = (hipStream_t)stream_back;
   const size_t nstate = (size_t)3 * batch * 128;
@@ -1436,7 +1444,14 @@ int ita_vitlstm_pipelined(ita_handle h, const void* const* image, int image_dtyp
   // because hipStreamWaitEvent must come after the hipEventRecord it refers to in HOST order.
   std::atomic<int> fronts_recorded{0}, backs_recorded{0}, abort_flag{0};
   int rc_back = ITA_OK;
-  std::thread back_thread([&]() {
+  std::string msg_back;     // the helper's error text (its fail() writes ITS thread-local message)
+  auto back_body = [&]() {
+    if (hipSetDevice(h->device) != hipSuccess) {   // a new thread starts on device 0
+      rc_back = fail(ITA_ERR_HIP, "hipSetDevice (back stream's host thread)");
+      msg_back = tl_msg;
+      abort_flag.store(1, std::memory_order_relaxed);
+      return;
+    }
     for (int t = 0; t < n_steps; ++t) {
       const int buf = t % ITA_PART_BUFFERS;
       while (fronts_recorded.load(std::memory_order_acquire) <= t) {
@@ -1450,8 +1465,17 @@ int ita_vitlstm_pipelined(ita_handle h, const void* const* image, int image_dtyp
       if (hipEventRecord(evb[buf], sb) != hipSuccess) { rc_back = fail(ITA_ERR_HIP, "hipEventRecord (back stream)"); break; }
       backs_recorded.store(t + 1, std::memory_order_release);
     }
-    if (rc_back) abort_flag.store(1, std::memory_order_relaxed);
-  });
+    if (rc_back) {
+      msg_back = tl_msg;
+      abort_flag.store(1, std::memory_order_relaxed);
+    }
+  };
+  std::thread back_thread;
+  try {
+    back_thread = std::thread(back_body);
+  } catch (const std::exception& e) {   // std::system_error must not escape through the C ABI
+    return fail(ITA_ERR_HIP, std::string("ita_vitlstm_pipelined: cannot start the back stream's host thread: ") + e.what());
+  }
   for (int t = 0; t < n_steps && !rc; ++t) {
     const int buf = t % ITA_PART_BUFFERS;
     if (t >= ITA_PART_BUFFERS) {   // front(t) overwrites what back(t - NB) read
@@ -1467,7 +1491,7 @@ int ita_vitlstm_pipelined(ita_handle h, const void* const* image, int image_dtyp
   if (rc) abort_flag.store(1, std::memory_order_relaxed);
   back_thread.join();
   if (rc) return rc;
-  if (rc_back) return fail(rc_back, "ita_vitlstm_pipelined: the back stream's host thread failed (see the earlier error)");
+  if (rc_back) return fail(rc_back, "ita_vitlstm_pipelined, back stream's host thread: " + msg_back);
   if (n_steps & 1) {   // an odd number of steps leaves the state in the internal copy
     HIPCHK(hipMemcpyAsync(state_h, sh[1], nstate * sizeof(float), hipMemcpyDeviceToDevice, sb));
     HIPCHK(hipMemcpyAsync(state_c, sc[1], nstate * sizeof(float), hipMemcpyDeviceToDevice, sb));

@@ -55,20 +55,33 @@ class VelocityGather:
     Equal shards (`frames_per_rank` on every rank: bench.py's weak-scaling form) or, with `total`, the uneven
     contiguous shards of shard_range(total, rank, world) (strong scaling: a global batch cut over the ranks): every
     rank then sends max-shard rows (its tail rows are padding) and `result` returns the `total` valid rows in stream
-    order.  `start` issues the collective for this step and returns immediately; `result` waits for it."""
+    order.  `sizes` gives the rows of every rank explicitly (a group of several steps of uneven shards: rank r sends
+    steps x shard_r rows).  `start` issues the collective for this step and returns immediately; `result` waits for it.
 
-    def __init__(self, frames_per_rank: int, world: int, device, dtype=None, total: Optional[int] = None):
+    `stage=True`: `start` first copies the caller's tensor into one of this object's own two send buffers (a
+    stream-ordered device copy), so the caller may overwrite its tensor as soon as `start` has returned -- for callers
+    with ONE velocity buffer (a captured HIP graph writes the same buffer on every replay).  Without it the caller
+    ping-pongs two buffers and calls `ready` before reusing one."""
+
+    def __init__(self, frames_per_rank: int, world: int, device, dtype=None, total: Optional[int] = None,
+                 sizes=None, stage: bool = False):
         import torch
         self.world = world
         dtype = dtype or torch.float32
-        if total is None:
+        if sizes is not None:
+            if len(sizes) != world or min(sizes) < 0:
+                raise ValueError("sizes: one non-negative row count per rank")
+            self.sizes = [int(s) for s in sizes]
+        elif total is None:
             self.sizes = [frames_per_rank] * world
         else:
             self.sizes = [hi - lo for lo, hi in (shard_range(total, r, world) for r in range(world))]
         self.n = max(self.sizes) if self.sizes else 0
         self.even = all(sz == self.n for sz in self.sizes)
+        self.stage = bool(stage)
         self.bufs = [torch.empty((world * self.n, 3), dtype=dtype, device=device) for _ in range(2)]
-        self.pad = None if self.even else [torch.zeros((self.n, 3), dtype=dtype, device=device) for _ in range(2)]
+        self.pad = (None if self.even and not self.stage
+                    else [torch.zeros((self.n, 3), dtype=dtype, device=device) for _ in range(2)])
         self.handles = [None, None]
         self.i = 0
 
@@ -84,7 +97,7 @@ class VelocityGather:
         i = self.i
         if self.handles[i] is not None:       # buffer about to be reused: its collective must be done
             self.handles[i].wait()
-        if vel.shape[0] != self.n:            # a short shard: send it padded to the longest one
+        if vel.shape[0] != self.n or self.stage:   # a short shard: send it padded to the longest one (stage: always copy)
             if self.pad is None or vel.shape[0] > self.n:
                 raise ValueError(f"velocity tensor has {vel.shape[0]} rows, the gather was built for {self.sizes}")
             self.pad[i][:vel.shape[0]].copy_(vel)

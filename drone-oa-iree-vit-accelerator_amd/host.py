@@ -154,6 +154,13 @@ def _torch():
     return torch
 
 
+def np_prod(shape) -> int:
+    n = 1
+    for d in shape:
+        n *= int(d)
+    return n
+
+
 def _stream_ptr(device=None):
     """handle of torch's current stream ON `device` (an Engine passes its own ordinal: the current stream of whatever
     device happens to be current would belong to another GPU)"""
@@ -187,8 +194,29 @@ class Engine:
         d = [C.c_int() for _ in range(6)]
         _chk(lib().ita_get_dims(self._h, *[C.byref(x) for x in d]))
         self.E, self.S, self.P, self.F, self.H, self.num_layers = [x.value for x in d]
+        self._reserved = 0          # frames the workspace is pinned for (ita_reserve); grows only
+        self._graphs = []           # weakrefs of live captured graphs: they hold raw workspace pointers
         if reserve:
-            _chk(lib().ita_reserve(self._h, reserve))
+            self.reserve(reserve)
+
+    def reserve(self, batch: int):
+        """Size and pin the workspace for `batch` frames (ita_reserve).  Growing it frees and reallocates every internal
+        buffer, which would leave a HIP graph captured earlier on this engine replaying freed pointers: refused while
+        such a graph is alive (build the largest graph first, or use one Engine per batch size)."""
+        batch = int(batch)
+        if batch <= self._reserved:
+            return
+        self._graphs = [g for g in self._graphs if g() is not None]
+        if self._graphs:
+            raise ITAError(f"reserve({batch}) would reallocate the workspace (pinned for {self._reserved} frames) under "
+                           f"{len(self._graphs)} live captured graph(s) of this engine: delete them first, or create the "
+                           "engine with reserve= the largest batch")
+        _chk(lib().ita_reserve(self._h, batch))
+        self._reserved = batch
+
+    def _track_graph(self, g):
+        import weakref
+        self._graphs.append(weakref.ref(g))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -405,9 +433,26 @@ class Engine:
     def pipelined(self, imgs, desvels, quats, state, vels, stream_front, stream_back):
         """n time steps pipelined on two torch streams by the library (ita_vitlstm_pipelined): imgs / desvels / quats /
         vels are sequences of per-step tensors (or a tensor with a leading step axis), state = (h, c) updated in place"""
+        torch = _torch()
         n = len(imgs)
+        if n < 1 or not (len(desvels) == len(quats) == len(vels) == n):
+            raise ITAError("pipelined: imgs / desvels / quats / vels must hold one tensor per step")
+        checked = [self._image(im) for im in imgs]       # device ordinal, (60, 90), dtype, contiguity -- as forward does
+        if len({dt for _, dt in checked}) != 1 or len({im.shape[0] for im, _ in checked}) != 1:
+            raise ITAError("pipelined: every step must have the same batch and image dtype")
+        imgs, dt = [im for im, _ in checked], checked[0][1]
         B = imgs[0].shape[0]
-        dt = 1 if imgs[0].dtype == _torch().uint8 else 0
+
+        def same(ts, shape, what):
+            out = []
+            for t in ts:
+                if not t.is_cuda or t.device.index != self.device or t.dtype != torch.float32 or not t.is_contiguous() \
+                        or t.numel() != int(np_prod(shape)):
+                    raise ITAError(f"pipelined: every {what} must be a contiguous f32 tensor of {shape} on cuda:{self.device}")
+                out.append(t)
+            return out
+        desvels, quats, vels = same(desvels, (B,), "desvel"), same(quats, (B, 4), "quat"), same(vels, (B, 3), "vel")
+        same(state, (3, B, 128), "state tensor")
         arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
         _chk(lib().ita_vitlstm_pipelined(self._h, arr(imgs), dt, arr(desvels), arr(quats), state[0].data_ptr(), state[1].data_ptr(),
                                          arr(vels), B, n, C.c_void_p(stream_front.cuda_stream), C.c_void_p(stream_back.cuda_stream)))
@@ -437,13 +482,20 @@ class Engine:
 
     def graphed_step(self, batch: int) -> "GraphedStep":
         """a HIP-graph replay of one time step with static buffers (see GraphedStep)"""
-        _chk(lib().ita_reserve(self._h, batch))
-        return GraphedStep(self, batch)
+        self.reserve(batch)
+        g = GraphedStep(self, batch)
+        self._track_graph(g)
+        return g
 
     def pipelined_steps(self, batch: int, n_steps: int = 8, stages: int = 3) -> "PipelinedSteps":
         """n_steps time steps per HIP-graph replay: encoder(t+2) | folded GEMM(t+1) | LSTM + fc(t) on three streams
         (stages = 2: front(t+1) | back(t) on two); see PipelinedSteps"""
-        return PipelinedSteps(self, batch, n_steps, stages)
+        if n_steps < 2 or stages not in (2, 3):
+            raise ITAError("pipelined_steps: n_steps >= 2 and stages in (2, 3)")
+        self.reserve(batch)
+        g = PipelinedSteps(self, batch, n_steps, stages)
+        self._track_graph(g)
+        return g
 
     # ---- drop-in symbols (host buffers) --------------------------------------------------
     def bind_dispatch(self, layer: int = 0, dtype: int = DISPATCH_F16):
@@ -513,7 +565,9 @@ class PipelinedSteps:
         torch = _torch()
         dev = torch.device("cuda", engine.device)
         self.engine, self.B, self.n, self.stages = engine, batch, n_steps, stages
-        _chk(lib().ita_reserve(engine._h, batch))
+        if n_steps < 2 or stages not in (2, 3):
+            raise ITAError("PipelinedSteps: n_steps >= 2 and stages in (2, 3)")
+        engine.reserve(batch)
         self.img = torch.zeros((n_steps, batch, 60, 90), dtype=torch.uint8, device=dev)
         self.desvel = torch.zeros((n_steps, batch), dtype=torch.float32, device=dev)
         self.quat = torch.zeros((n_steps, batch, 4), dtype=torch.float32, device=dev)

@@ -263,8 +263,16 @@ def _lstm_reorder(w: np.ndarray) -> np.ndarray:
 
 
 def match_itavitlstm(model: Model) -> dict:
-    """Checks that `model` is the reference's ITAViTLSTM marker export and returns
-    {"E", "num_layers", "markers": [(node index, tensor)], "float_params": {reference state_dict name: array}}."""
+    """Checks that `model` is one of the reference's marker exports and returns
+    {"E", "num_layers", "has_tail", "markers": [(node index, tensor)], "marker_kinds": ["attention" | "ffn" | "block"],
+     "float_params": {state_dict-style name: array}}.  Two graph families:
+      * ITAViTLSTM (models/ITA_single_layer_upsample_shuffle/export/model.py): E = 64, one layer, `x + x` markers, the
+        3x3 fusion conv and a 4608 -> 512 decoder;
+      * the no-tail family (models/ITA/export/ITA_ONNX.py:22-38,41-115 -- the graph ITA_spec.mlir:69-85 matches -- and its
+        single-layer member): E = 128, `neg` (attention) / `abs` (feed-forward) markers, one or two layers, no 3x3 conv,
+        decoder Linear(E * 128 -> 512) on the flattened tokens.
+    LayerNorm parameters come back under this repo's `norms1.l` / `norms2.l` keys whatever the exporting module called
+    its ModuleLists (`norm1_layers` in ITA_ONNX.py:61-62)."""
     if model.opset and model.opset < 17:
         raise OnnxShimError(f"opset {model.opset}: the reference exports opset 17 (LayerNormalization)")
     if tuple(n for n, _ in model.inputs) != IO_INPUTS:
@@ -276,7 +284,7 @@ def match_itavitlstm(model: Model) -> dict:
         raise OnnxShimError(f"image shape {shp['image']} is not (B, 1, 60, 90)")
     if shp["hidden_in_h"] is not None and (shp["hidden_in_h"][0] != 3 or shp["hidden_in_h"][2] != 128):
         raise OnnxShimError(f"hidden_in_h shape {shp['hidden_in_h']} is not (3, B, 128)")
-    fp, markers = {}, []
+    fp, markers, kinds = {}, [], []
     convs, lns, lstms, linears = [], [], [], []
     for idx, n in enumerate(model.nodes):
         if n.op_type == "Conv":
@@ -289,21 +297,25 @@ def match_itavitlstm(model: Model) -> dict:
             linears.append((idx, n))
         elif n.op_type == "Add" and len(n.inputs) == 2 and n.inputs[0] == n.inputs[1]:
             markers.append((idx, n.inputs[0]))           # DummyHardwareBlock: x + x (export/model.py:29)
+            kinds.append("block")                        # (attention or feed-forward by position)
         elif n.op_type in ("Neg", "Abs"):
             markers.append((idx, n.inputs[0]))           # ITA_ONNX.py:26 (attention), :38 (feed-forward)
+            kinds.append("attention" if n.op_type == "Neg" else "ffn")
     # tokenizer conv 7x7 stride 2 and fusion conv 3x3
     tok = [c for c in convs if (_const_of(model, c.inputs[1]) is not None and _const_of(model, c.inputs[1]).shape[2:] == (7, 7))]
     dwn = [c for c in convs if (_const_of(model, c.inputs[1]) is not None and _const_of(model, c.inputs[1]).shape[2:] == (3, 3))]
-    if len(tok) != 1 or len(dwn) != 1:
-        raise OnnxShimError(f"expected one 7x7 and one 3x3 Conv, found {len(tok)} and {len(dwn)}")
+    if len(tok) != 1 or len(dwn) > 1:
+        raise OnnxShimError(f"expected one 7x7 Conv and at most one 3x3 Conv, found {len(tok)} and {len(dwn)}")
+    has_tail = len(dwn) == 1
     wt = _const_of(model, tok[0].inputs[1])
     E = int(wt.shape[0])
     if wt.shape != (E, 1, 7, 7) or list(tok[0].attrs.get("strides", [])) != [2, 2] or list(tok[0].attrs.get("pads", [])) != [3, 3, 3, 3]:
         raise OnnxShimError("tokenizer Conv is not Conv2d(1, E, 7, stride 2, padding 3) (layers.py:30-37)")
-    wd = _const_of(model, dwn[0].inputs[1])
-    if wd.shape != (9, E // 4 + E, 3, 3) or list(dwn[0].attrs.get("pads", [])) != [1, 1, 1, 1]:
-        raise OnnxShimError(f"fusion Conv weight {wd.shape} is not (9, 5E/4, 3, 3) with padding 1 (QAT/model.py:90)")
-    for key, c in (("tokenizer.conv", tok[0]), ("down_sample", dwn[0])):
+    if has_tail:
+        wd = _const_of(model, dwn[0].inputs[1])
+        if wd.shape != (9, E // 4 + E, 3, 3) or list(dwn[0].attrs.get("pads", [])) != [1, 1, 1, 1]:
+            raise OnnxShimError(f"fusion Conv weight {wd.shape} is not (9, 5E/4, 3, 3) with padding 1 (QAT/model.py:90)")
+    for key, c in (("tokenizer.conv", tok[0]),) + ((("down_sample", dwn[0]),) if has_tail else ()):
         if len(c.inputs) < 3 or _const_of(model, c.inputs[2]) is None:
             raise OnnxShimError(f"{key}: Conv without a constant bias")
         fp[key + ".weight"] = np.asarray(_const_of(model, c.inputs[1]), np.float32)
@@ -322,7 +334,11 @@ def match_itavitlstm(model: Model) -> dict:
         fp[nm + ".weight"], fp[nm + ".bias"] = np.asarray(s, np.float32), np.asarray(b, np.float32)
     if len(markers) != 2 * L:
         raise OnnxShimError(f"{len(markers)} marker ops (x + x / neg / abs): expected {2 * L} (attention, feed-forward per layer)")
-    # linears: decoder (4608 -> 512) and fc (128 -> 3)
+    for j, k in enumerate(kinds):                        # neg / abs must sit at their own block's position
+        want = "attention" if j % 2 == 0 else "ffn"
+        if k not in ("block", want):
+            raise OnnxShimError(f"marker {j} is a {k} marker at a {want} position (ITA_ONNX.py:100-107: attention, then feed-forward)")
+    # linears: decoder (4608 -> 512 behind the fusion tail, E * 128 -> 512 on the flattened tokens) and fc (128 -> 3)
     def linear(n_in, n_out, key):
         for idx, n in linears:
             w = _const_of(model, n.inputs[1])
@@ -350,7 +366,7 @@ def match_itavitlstm(model: Model) -> dict:
             fp[key + ".bias"] = np.asarray(b, np.float32)
             return
         raise OnnxShimError(f"{key}: no Gemm / MatMul of shape {n_in} -> {n_out}")
-    linear(4608, 512, "decoder")
+    linear(4608 if has_tail else E * 128, 512, "decoder")
     linear(128, 3, "nn_fc2")
     if len(lstms) != 3:
         raise OnnxShimError(f"{len(lstms)} LSTM nodes: expected 3 (nn.LSTM(517, 128, num_layers=3), QAT/model.py:84)")
@@ -365,4 +381,115 @@ def match_itavitlstm(model: Model) -> dict:
         fp[f"lstm.weight_hh_l{l}"] = _lstm_reorder(np.asarray(R[0], np.float32))
         fp[f"lstm.bias_ih_l{l}"] = _lstm_reorder(np.asarray(B[0, :512], np.float32))
         fp[f"lstm.bias_hh_l{l}"] = _lstm_reorder(np.asarray(B[0, 512:], np.float32))
-    return {"E": E, "num_layers": L, "markers": markers, "float_params": fp}
+    return {"E": E, "num_layers": L, "has_tail": has_tail, "markers": markers,
+            "marker_kinds": [("attention" if j % 2 == 0 else "ffn") if k == "block" else k for j, k in enumerate(kinds)],
+            "float_params": fp}
+
+
+# --------------------------------------------------------------------------------- the marker graph as MLIR text
+# `iree-import-onnx model.onnx --opset-version 17 -o model.mlir` (tests/export_onnx_for_FPGA.py:86-89) is the second entry
+# point: the same marker graph as text.  Two textual forms carry the markers, and both are read here:
+#   * torch-onnx dialect (what iree-import-onnx writes):   torch.operator "onnx.Neg"(%x) : (!torch.vtensor<[1,128,128],f32>) -> ...
+#   * linalg on tensors (what the transform spec matches, ITA_spec.mlir:69-85):
+#         linalg.generic {...} ins(%x : tensor<1x128x128xf32>) outs(...) { ^bb0(...): %r = arith.negf %in : f32 ; linalg.yield %r }
+#     with `math.absf` for the feed-forward marker (the reference ships no matcher for it) and
+#     `arith.addf %in, %in` for the E = 64 export's `x + x`.
+# Weights are not taken from MLIR text (they are dense resources there); this reader answers WHICH dispatches a module
+# needs: marker kind, position and tensor shape, i.e. E, the number of layers and which plugin entry each marker gets.
+import re as _re
+
+_MLIR_SHAPE_VT = _re.compile(r"!torch\.vtensor<\[([0-9,\s]+)\],\s*f(?:32|16)>")
+_MLIR_SHAPE_T = _re.compile(r"tensor<((?:\d+x)+)f(?:32|16)>")
+_MLIR_ONNX_OP = _re.compile(r'torch\.operator\s+"onnx\.(Neg|Abs|Add)"\s*\(([^)]*)\)\s*:\s*\(([^)]*)\)')
+
+
+def scan_mlir_markers(text: str) -> List[dict]:
+    """-> [{"kind": "attention" | "ffn" | "block", "op": ..., "shape": (1, S, E), "form": "onnx" | "linalg", "line": n}]
+    in textual order.  Raises OnnxShimError on text that holds a marker op whose tensor type cannot be read."""
+    out = []
+    lines = text.splitlines()
+    i = 0
+    while i < len(lines):
+        ln = lines[i]
+        m = _MLIR_ONNX_OP.search(ln)
+        if m:
+            op, args, types = m.group(1), [a.strip() for a in m.group(2).split(",")], m.group(3)
+            if op == "Add" and not (len(args) == 2 and args[0] == args[1]):
+                i += 1
+                continue                                  # an ordinary residual add
+            sh = _MLIR_SHAPE_VT.search(types)
+            if not sh:
+                raise OnnxShimError(f"line {i + 1}: onnx.{op} marker without a static !torch.vtensor type")
+            shape = tuple(int(x) for x in sh.group(1).replace(" ", "").split(",") if x)
+            out.append({"kind": {"Neg": "attention", "Abs": "ffn", "Add": "block"}[op], "op": "onnx." + op, "shape": shape,
+                        "form": "onnx", "line": i + 1})
+            i += 1
+            continue
+        if "linalg.generic" in ln:
+            # gather the op up to the end of its region: the closing "} -> tensor<...>" line
+            j, body = i, []
+            while j < len(lines):
+                body.append(lines[j])
+                if _re.search(r"\}\s*->\s*tensor<", lines[j]):
+                    break
+                j += 1
+            blob = "\n".join(body)
+            ops_in = _re.findall(r"=\s*((?:arith|math)\.[a-z_0-9]+)\b([^\n]*)", blob)
+            payload = [(o, rest) for o, rest in ops_in if not o.startswith("arith.constant")]
+            kind = None
+            if len(payload) == 1:
+                o, rest = payload[0]
+                if o == "arith.negf":
+                    kind = "attention"
+                elif o == "math.absf":
+                    kind = "ffn"
+                elif o == "arith.addf":
+                    a = [x.strip() for x in rest.split(":")[0].split(",")]
+                    if len(a) == 2 and a[0] == a[1]:
+                        kind = "block"
+            ins_one = len(_re.findall(r"ins\(([^)]*)\)", blob)) == 1 and "," not in _re.findall(r"ins\(([^:)]*)", blob)[0]
+            if kind and ins_one:
+                sh = _MLIR_SHAPE_T.search(_re.findall(r"ins\(([^)]*)\)", blob)[0])
+                if not sh:
+                    raise OnnxShimError(f"line {i + 1}: marker linalg.generic without a static tensor type")
+                shape = tuple(int(x) for x in sh.group(1).split("x") if x)
+                out.append({"kind": kind, "op": payload[0][0], "shape": shape, "form": "linalg", "line": i + 1})
+            i = j + 1
+            continue
+        i += 1
+    return out
+
+
+def match_mlir(text: str) -> dict:
+    """Recognises a marker module: -> {"E", "S", "num_layers", "markers": scan_mlir_markers(text), "dispatch": [...]}
+    where dispatch[j] names the plugin symbol marker j is routed to (include/ita_mi355x.h): `ITASelfAttention_workgroup`
+    for attention markers (the symbol ITA_spec.mlir:30-33 imports), `ITAFeedForward_workgroup` for feed-forward ones.
+    Checks: an even number of markers alternating attention / feed-forward, one (1, 128, E) shape throughout with
+    E in {64, 128}, and -- when the text has a `func.func @main_graph` -- its five inputs (export_onnx_for_FPGA.py:78)."""
+    mk = scan_mlir_markers(text)
+    if not mk or len(mk) % 2:
+        raise OnnxShimError(f"{len(mk)} marker ops found: expected two per encoder layer (attention, feed-forward)")
+    shapes = {m["shape"] for m in mk}
+    if len(shapes) != 1:
+        raise OnnxShimError(f"markers of different shapes {sorted(shapes)}")
+    shape = next(iter(shapes))
+    if len(shape) != 3 or shape[1] != 128 or shape[2] not in (64, 128):
+        raise OnnxShimError(f"marker tensor shape {shape} is not (B, 128, E) with E in (64, 128)")
+    for j, m in enumerate(mk):
+        want = "attention" if j % 2 == 0 else "ffn"
+        if m["kind"] not in ("block", want):
+            raise OnnxShimError(f"marker {j} (line {m['line']}) is a {m['kind']} marker at a {want} position")
+    sig = _re.search(r"func\.func\s+@main_graph\s*\(([^{]*?)\)\s*->", text, _re.S)
+    if sig:
+        args = _re.findall(r"(%[\w.]+)\s*:\s*(![\w.]+<[^>]*>|tensor<[^>]*>)", sig.group(1))
+        if len(args) != 5:
+            raise OnnxShimError(f"@main_graph takes {len(args)} tensors: expected the five of {list(IO_INPUTS)}")
+        t0 = args[0][1]
+        dims = (_MLIR_SHAPE_VT.search(t0) or _MLIR_SHAPE_T.search(t0))
+        if dims:
+            d = [int(x) for x in _re.split(r"[x,]", dims.group(1).replace(" ", "")) if x]
+            if d[1:] != [1, 60, 90]:
+                raise OnnxShimError(f"@main_graph image argument {t0} is not (B, 1, 60, 90)")
+    kinds = [("attention" if j % 2 == 0 else "ffn") for j in range(len(mk))]
+    return {"E": shape[2], "S": shape[1], "num_layers": len(mk) // 2, "markers": mk,
+            "dispatch": ["ITASelfAttention_workgroup" if k == "attention" else "ITAFeedForward_workgroup" for k in kinds]}

@@ -330,6 +330,32 @@ int ita_oracle_mha(const float* x, int B, int S, int E, int P, const int8_t* wq,
   return 0;
 }
 
+/* The same block at the accelerator's own boundary: int8 codes in (what attention_blocks.N.quant produces), out_proj's
+ * int8 codes out (layers.py:106-123 without the QuantStub / DeQuantStub at :103,:125).  Lets a test hand ARBITRARY codes
+ * to the int8-in GPU entry (ita_mha_q8) without a float round trip that may not reproduce them. */
+int ita_oracle_mha_q8(const int8_t* xq, int B, int S, int E, int P, const int8_t* wq, const int32_t* bq,
+                      const int8_t* wk, const int32_t* bk, const int8_t* wv, const int32_t* bv, const int8_t* wo,
+                      const int32_t* bo, const float* scal, int8_t* out_q) {
+  int8_t* Q = (int8_t*)malloc((size_t)S * P);
+  int8_t* K = (int8_t*)malloc((size_t)S * P);
+  int8_t* V = (int8_t*)malloc((size_t)S * P);
+  int8_t* L = (int8_t*)malloc((size_t)S * S);
+  uint8_t* A = (uint8_t*)malloc((size_t)S * S);
+  int8_t* C = (int8_t*)malloc((size_t)S * P);
+  for (int b = 0; b < B; ++b) {
+    const int8_t* x = xq + (size_t)b * S * E;
+    ita_oracle_linear_q(x, S, E, P, wq, bq, scal[ITA_A_MQ], 0, Q);
+    ita_oracle_linear_q(x, S, E, P, wk, bk, scal[ITA_A_MK], 0, K);
+    ita_oracle_linear_q(x, S, E, P, wv, bv, scal[ITA_A_MV], 0, V);
+    ita_oracle_matmul_qk(Q, K, S, P, scal[ITA_A_ML], L);
+    ita_oracle_softmax(L, S, S, A);
+    ita_oracle_matmul_av(A, V, S, P, scal[ITA_A_MC], C);
+    ita_oracle_linear_q(C, S, P, E, wo, bo, scal[ITA_A_MO], 0, out_q + (size_t)b * S * E);
+  }
+  free(Q); free(K); free(V); free(L); free(A); free(C);
+  return 0;
+}
+
 /* ITAFeedForward_QAT.forward */
 int ita_oracle_ffn(const float* x, int B, int S, int E, int F, const int8_t* w1, const int32_t* b1,
                    const int8_t* w2, const int32_t* b2, const float* scal, float* out_f, int8_t* t_xq,

@@ -105,6 +105,18 @@ def mha(x, t, i=0, taps=False):
     return (out, tp) if taps else out
 
 
+def mha_q8(x_q, t, i=0):
+    """the attention block on int8 codes: x_q (B,S,E) int8 -> out_proj codes (B,S,E) int8 (ita_oracle_mha_q8)"""
+    x_q = _c(x_q, np.int8)
+    B, S, E = x_q.shape
+    P = t[f"attn{i}.wq"].shape[0]
+    out = np.empty_like(x_q)
+    lib().ita_oracle_mha_q8(_p(x_q), B, S, E, P, _p(t[f"attn{i}.wq"]), _p(t[f"attn{i}.bq"]), _p(t[f"attn{i}.wk"]),
+                            _p(t[f"attn{i}.bk"]), _p(t[f"attn{i}.wv"]), _p(t[f"attn{i}.bv"]), _p(t[f"attn{i}.wo"]),
+                            _p(t[f"attn{i}.bo"]), _p(t[f"attn{i}.scal"]), _p(out))
+    return out
+
+
 def ffn(x, t, i=0, taps=False):
     x = _c(x, np.float32)
     B, S, E = x.shape

@@ -91,3 +91,63 @@ def test_two_rank_gather_matches_single_process(oracle, total):
     for s in range(steps):
         vel, h, c = oracle.forward(blob, fr["img_u8"], fr["desvel"] + s, fr["quat"], h, c)
         np.testing.assert_array_equal(got[s], vel)       # rank order == stream order, bit for bit
+
+
+def _group_worker(rank, world, port, total, ngroup, groups, q):
+    """the graph / --gather-every 8 schedule of bench.py on CPU: every rank owns ONE velocity buffer of ngroup steps x its
+    shard that it overwrites for every group (as a captured HIP graph does), the gather is built with explicit per-rank
+    sizes (uneven shards padded to the longest) and stage=True (its own ping-pong send buffers)"""
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from drone_oa_iree_vit_accelerator_amd import dist as itd
+    itd.init("gloo")
+    shard = [hi - lo for lo, hi in (itd.shard_range(total, r, world) for r in range(world))]
+    lo, hi = itd.shard_range(total, rank, world)
+    n = hi - lo
+    gather = itd.VelocityGather(ngroup * n, world, torch.device("cpu"), sizes=[ngroup * s for s in shard], stage=True)
+    vel = torch.empty((ngroup, n, 3))                       # the one buffer
+    outs, pending = [], None
+    for g in range(groups):
+        for k in range(ngroup):                             # "replay": overwrite the buffer while the last all-gather may run
+            step = g * ngroup + k
+            vel[k] = (torch.arange(lo, hi, dtype=torch.float32).reshape(n, 1) * 1000 + step) + torch.tensor([0.0, 0.25, 0.5])
+        if pending is not None:
+            outs.append(gather.result(pending).clone())
+        pending = gather.start(vel.reshape(ngroup * n, 3))
+    outs.append(gather.result(pending).clone())
+    gather.finish()
+    dist.barrier()
+    if rank == 0:
+        q.put([o.numpy() for o in outs])
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total,world", [(5, 2), (8, 2), (7, 3)], ids=["uneven2", "even2", "uneven3"])
+def test_grouped_staged_gather_with_uneven_shards(total, world):
+    ngroup, groups = 4, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_group_worker, args=(r, world, port, total, ngroup, groups, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(got) == groups
+    for g in range(groups):
+        rows = []
+        for r in range(world):                              # rank-major, then step, then stream: what each rank sent
+            lo, hi = itadist.shard_range(total, r, world)
+            for k in range(ngroup):
+                step = g * ngroup + k
+                rows.append(np.arange(lo, hi, dtype=np.float32).reshape(-1, 1) * 1000 + step + np.array([0.0, 0.25, 0.5], np.float32))
+        np.testing.assert_array_equal(got[g], np.concatenate(rows, 0))
+
+
+def test_gather_rejects_bad_sizes():
+    with pytest.raises(ValueError):
+        itadist.VelocityGather(4, 2, torch.device("cpu"), sizes=[4])

@@ -116,6 +116,20 @@ def test_attention_block_end_to_end(oracle, path):
 
 
 @pytest.mark.parametrize("path", FIX_ALL, ids=_ids(FIX_ALL))
+def test_attention_block_int8_entry(oracle, path):
+    """ita_oracle_mha_q8 (int8 codes in, out_proj codes out: the checker of the GPU's ita_mha_q8) from the REFERENCE's
+    own quantised block input: equals the taps of the float-in entry, and the reference's out_q except in rows a
+    near-tie logit touches."""
+    d = params.load_fixture(path)
+    t = params.attention_tensors(d, "attn0.", 0)
+    got = oracle.mha_q8(d["s0.attn0.x_q"], t)
+    _, tp = oracle.mha(d["s0.attn0.x_q.in"], t, taps=True)
+    np.testing.assert_array_equal(got, tp["out_q"])
+    rows_ok = (tp["logits"] == d["s0.attn0.probs.in"][:, 0]).all(axis=-1)
+    np.testing.assert_array_equal(got[rows_ok], d["s0.attn0.out_q"][rows_ok])
+
+
+@pytest.mark.parametrize("path", FIX_ALL, ids=_ids(FIX_ALL))
 def test_ffn_block(oracle, path):
     d = params.load_fixture(path)
     t = params.ffn_tensors(d, "ffn0.", 0)
