@@ -341,6 +341,199 @@ __device__ __forceinline__ void lg8_b(const i32x4 (&acc)[2], float mult, unsigne
     bits[2 * k] = __float_as_uint(v.x); bits[2 * k + 1] = __float_as_uint(v.y);
   }
 }
+// ---- round-3 requantisation of biased accumulators: the clamp moves behind the rounding, into the integer domain, where
+// ONE instruction saturates two values (v_sat_pk_u8_i16) -- 2.75 VALU instructions per value instead of 3.0, and 2.25 where a
+// load-time proof allows the single-rounding form:
+//   exact : x = acc_bits - 1.5*2^23 (v_pk_add_f32, exact) ; y = fl(x * m) (v_pk_mul_f32: the reference's first rounding) ;
+//           t = y + (1.5*2^23 + 128) (v_pk_add_f32: rounds to nearest-even INTEGER, the reference's second rounding; the low
+//           16 bits of t's pattern are then r + 128 in two's complement, r = rne(y), provided |r + 128| < 2^15 -- checked per
+//           weight row at load time, stream_range_ok) ; pairs of low halves -> one dword (v_perm_b32) ; u8 saturation of
+//           both halves = clamp(r, -128, 127) + 128 (v_sat_pk_u8_i16, SDWA places the two bytes) ; ^ 0x80808080 per dword.
+//   fast  : t = fma(x, m, 1.5*2^23 + 128) in ONE v_pk_fma_f32 -- a single rounding of the exact product.  It differs from
+//           the reference's two roundings only for accumulator values whose exact product lies within half an ulp of a
+//           rounding tie without being one; ita_load_weights enumerates every accumulator value of the clamp range for the
+//           site's multiplier (fast_site_ok) and enables this form only when none differs.
+//   relu  : the exact form with the lower clamp moved into the multiply: y/256 = fl(x * (m/256)) with the VOP3P clamp
+//           modifier ([0, 1] <-> y in [0, 256]), t = y/256 + (1.5*2^23 + 128)/256 (ulp 2^-8: same integer rounding, same low
+//           bits), the u8 saturation then gives min(r, 127) + 128.
+#define ITA_MAGIC128_F 12583040.0f        /* 1.5 * 2^23 + 128 */
+#define ITA_MAGIC32K_F 12615680.0f        /* 1.5 * 2^23 + 32768: low 16 bits = r + 32768 = r ^ 0x8000 (order-preserving u16) */
+enum { ITA_RQ_EXACT = 0, ITA_RQ_FAST = 1, ITA_RQ_RELU = 2 };
+
+template <int NP, int MODE>   // NP register pairs: acc bit patterns -> float patterns whose low 16 bits hold rne(acc * mult) + bias
+__device__ __forceinline__ void pk_requant_round(f32x2 (&x)[NP], float mult, float magic) {
+  static_assert(NP == 8 || NP == 4, "");
+  const f32x2 c2 = {-ITA_MAGIC_F, -ITA_MAGIC_F};
+  if constexpr (MODE == ITA_RQ_FAST) {
+    // (an instruction reads at most one SGPR operand: the magic constant is copied into a VGPR pair inside the block -- as a
+    //  loop-invariant VGPR pair the compiler would hoist it out of the frame loop and, at 256 registers, spill it)
+    const f32x2 m2 = {mult, mult}, g2s = {magic, magic};
+    f32x2 g2;
+    if constexpr (NP == 8) {
+      asm("s_nop 7\n\ts_nop 1\n\t"
+        "v_pk_mov_b32 %8, %11, %11\n\t"
+        "v_pk_add_f32 %0, %0, %9\n\t"
+        "v_pk_add_f32 %1, %1, %9\n\t"
+        "v_pk_add_f32 %2, %2, %9\n\t"
+        "v_pk_add_f32 %3, %3, %9\n\t"
+        "v_pk_add_f32 %4, %4, %9\n\t"
+        "v_pk_add_f32 %5, %5, %9\n\t"
+        "v_pk_add_f32 %6, %6, %9\n\t"
+        "v_pk_add_f32 %7, %7, %9\n\t"
+        "v_pk_fma_f32 %0, %0, %10, %8\n\t"
+        "v_pk_fma_f32 %1, %1, %10, %8\n\t"
+        "v_pk_fma_f32 %2, %2, %10, %8\n\t"
+        "v_pk_fma_f32 %3, %3, %10, %8\n\t"
+        "v_pk_fma_f32 %4, %4, %10, %8\n\t"
+        "v_pk_fma_f32 %5, %5, %10, %8\n\t"
+        "v_pk_fma_f32 %6, %6, %10, %8\n\t"
+        "v_pk_fma_f32 %7, %7, %10, %8"
+          : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "=&v"(g2)
+          : "s"(c2), "s"(m2), "s"(g2s));
+    } else {
+      asm("s_nop 7\n\ts_nop 1\n\t"
+        "v_pk_mov_b32 %4, %7, %7\n\t"
+        "v_pk_add_f32 %0, %0, %5\n\t"
+        "v_pk_add_f32 %1, %1, %5\n\t"
+        "v_pk_add_f32 %2, %2, %5\n\t"
+        "v_pk_add_f32 %3, %3, %5\n\t"
+        "v_pk_fma_f32 %0, %0, %6, %4\n\t"
+        "v_pk_fma_f32 %1, %1, %6, %4\n\t"
+        "v_pk_fma_f32 %2, %2, %6, %4\n\t"
+        "v_pk_fma_f32 %3, %3, %6, %4"
+          : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "=&v"(g2)
+          : "s"(c2), "s"(m2), "s"(g2s));
+    }
+  } else {
+    // (RELU: the caller passes mult / 256 and magic / 256 -- both exact power-of-two scalings)
+    const f32x2 m2 = {mult, mult}, g2 = {magic, magic};
+    if constexpr (NP == 8) {
+      if constexpr (MODE == ITA_RQ_RELU) {
+        asm("s_nop 7\n\ts_nop 1\n\t"
+          "v_pk_add_f32 %0, %0, %8\n\t"
+          "v_pk_add_f32 %1, %1, %8\n\t"
+          "v_pk_add_f32 %2, %2, %8\n\t"
+          "v_pk_add_f32 %3, %3, %8\n\t"
+          "v_pk_add_f32 %4, %4, %8\n\t"
+          "v_pk_add_f32 %5, %5, %8\n\t"
+          "v_pk_add_f32 %6, %6, %8\n\t"
+          "v_pk_add_f32 %7, %7, %8\n\t"
+          "v_pk_mul_f32 %0, %0, %9 clamp\n\t"
+          "v_pk_mul_f32 %1, %1, %9 clamp\n\t"
+          "v_pk_mul_f32 %2, %2, %9 clamp\n\t"
+          "v_pk_mul_f32 %3, %3, %9 clamp\n\t"
+          "v_pk_mul_f32 %4, %4, %9 clamp\n\t"
+          "v_pk_mul_f32 %5, %5, %9 clamp\n\t"
+          "v_pk_mul_f32 %6, %6, %9 clamp\n\t"
+          "v_pk_mul_f32 %7, %7, %9 clamp\n\t"
+          "v_pk_add_f32 %0, %0, %10\n\t"
+          "v_pk_add_f32 %1, %1, %10\n\t"
+          "v_pk_add_f32 %2, %2, %10\n\t"
+          "v_pk_add_f32 %3, %3, %10\n\t"
+          "v_pk_add_f32 %4, %4, %10\n\t"
+          "v_pk_add_f32 %5, %5, %10\n\t"
+          "v_pk_add_f32 %6, %6, %10\n\t"
+          "v_pk_add_f32 %7, %7, %10"
+            : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])
+            : "s"(c2), "s"(m2), "s"(g2));
+      } else {
+        asm("s_nop 7\n\ts_nop 1\n\t"
+          "v_pk_add_f32 %0, %0, %8\n\t"
+          "v_pk_add_f32 %1, %1, %8\n\t"
+          "v_pk_add_f32 %2, %2, %8\n\t"
+          "v_pk_add_f32 %3, %3, %8\n\t"
+          "v_pk_add_f32 %4, %4, %8\n\t"
+          "v_pk_add_f32 %5, %5, %8\n\t"
+          "v_pk_add_f32 %6, %6, %8\n\t"
+          "v_pk_add_f32 %7, %7, %8\n\t"
+          "v_pk_mul_f32 %0, %0, %9\n\t"
+          "v_pk_mul_f32 %1, %1, %9\n\t"
+          "v_pk_mul_f32 %2, %2, %9\n\t"
+          "v_pk_mul_f32 %3, %3, %9\n\t"
+          "v_pk_mul_f32 %4, %4, %9\n\t"
+          "v_pk_mul_f32 %5, %5, %9\n\t"
+          "v_pk_mul_f32 %6, %6, %9\n\t"
+          "v_pk_mul_f32 %7, %7, %9\n\t"
+          "v_pk_add_f32 %0, %0, %10\n\t"
+          "v_pk_add_f32 %1, %1, %10\n\t"
+          "v_pk_add_f32 %2, %2, %10\n\t"
+          "v_pk_add_f32 %3, %3, %10\n\t"
+          "v_pk_add_f32 %4, %4, %10\n\t"
+          "v_pk_add_f32 %5, %5, %10\n\t"
+          "v_pk_add_f32 %6, %6, %10\n\t"
+          "v_pk_add_f32 %7, %7, %10"
+            : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])
+            : "s"(c2), "s"(m2), "s"(g2));
+      }
+    } else {
+      static_assert(MODE != ITA_RQ_RELU, "the ReLU site has 8 pairs");
+      asm("s_nop 7\n\ts_nop 1\n\t"
+        "v_pk_add_f32 %0, %0, %4\n\t"
+        "v_pk_add_f32 %1, %1, %4\n\t"
+        "v_pk_add_f32 %2, %2, %4\n\t"
+        "v_pk_add_f32 %3, %3, %4\n\t"
+        "v_pk_mul_f32 %0, %0, %5\n\t"
+        "v_pk_mul_f32 %1, %1, %5\n\t"
+        "v_pk_mul_f32 %2, %2, %5\n\t"
+        "v_pk_mul_f32 %3, %3, %5\n\t"
+        "v_pk_add_f32 %0, %0, %6\n\t"
+        "v_pk_add_f32 %1, %1, %6\n\t"
+        "v_pk_add_f32 %2, %2, %6\n\t"
+        "v_pk_add_f32 %3, %3, %6"
+          : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])
+          : "s"(c2), "s"(m2), "s"(g2));
+    }
+  }
+}
+// eight dwords of two 16-bit (r + 128) values each -> four dwords of four int8 codes: u8 saturation of both halves
+// (= clamp(r, -128, 127) + 128), SDWA places the byte pair in the low / high word, ^ 0x80 per byte.  Same SDWA hazard rule
+// as round_pack16: four destinations interleaved, one wait state at the end.
+__device__ __forceinline__ i32x4 sat_pack16(const unsigned (&w)[8]) {
+  unsigned p0, p1, p2, p3;
+  const unsigned flip = 0x80808080u;
+  asm(
+      "v_sat_pk_u8_i16_sdwa %0, %4 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"
+      "v_sat_pk_u8_i16_sdwa %1, %6 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"
+      "v_sat_pk_u8_i16_sdwa %2, %8 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"
+      "v_sat_pk_u8_i16_sdwa %3, %10 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"
+      "v_sat_pk_u8_i16_sdwa %0, %5 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+      "v_sat_pk_u8_i16_sdwa %1, %7 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+      "v_sat_pk_u8_i16_sdwa %2, %9 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+      "v_sat_pk_u8_i16_sdwa %3, %11 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+      "v_xor_b32 %0, %12, %0\n\t"
+      "v_xor_b32 %1, %12, %1\n\t"
+      "v_xor_b32 %2, %12, %2\n\t"
+      "v_xor_b32 %3, %12, %3\n\t"
+      "s_nop 0"
+      : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3)
+      : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "s"(flip));
+  return (i32x4){(int)p0, (int)p1, (int)p2, (int)p3};
+}
+// requantise + pack sixteen biased accumulators (four 16x16 tiles): byte 4t + i of the result <-> acc[t][i]
+template <int MODE>
+__device__ __forceinline__ i32x4 rq_pack16_v3(const i32x4 (&acc)[4], float mult) {
+  f32x2 x[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x[k] = (f32x2){__int_as_float(acc[k >> 1][2 * (k & 1)]), __int_as_float(acc[k >> 1][2 * (k & 1) + 1])};
+  if constexpr (MODE == ITA_RQ_RELU) pk_requant_round<8, MODE>(x, mult * 0.00390625f, ITA_MAGIC128_F * 0.00390625f);
+  else pk_requant_round<8, MODE>(x, mult, ITA_MAGIC128_F);
+  unsigned w[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)   // {lo16(x.x), lo16(x.y)}
+    w[k] = __builtin_amdgcn_perm(__float_as_uint(x[k].y), __float_as_uint(x[k].x), 0x05040100u);
+  return sat_pack16(w);
+}
+// logits: eight biased accumulators (two key tiles) -> four dwords of two ORDER-PRESERVING u16 each: rne(acc * mult) + 32768,
+// unclamped (the integer softmax clamps: ita_softmax_packed16).  Pair k <-> acc[k >> 1][2 (k & 1)], [.. + 1].
+template <int MODE>
+__device__ __forceinline__ void lg8_v3(const i32x4 (&acc)[2], float mult, unsigned (&w)[4]) {
+  f32x2 x[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) x[k] = (f32x2){__int_as_float(acc[k >> 1][2 * (k & 1)]), __int_as_float(acc[k >> 1][2 * (k & 1) + 1])};
+  pk_requant_round<4, MODE>(x, mult, ITA_MAGIC32K_F);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w[k] = __builtin_amdgcn_perm(__float_as_uint(x[k].y), __float_as_uint(x[k].x), 0x05040100u);
+}
 template <typename ACC>
 __device__ __forceinline__ void rq_pack16(const ACC& acc, float mult, float lo, unsigned (&pk)[4]) {
   float f[16];

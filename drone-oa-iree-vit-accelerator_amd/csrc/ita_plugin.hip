@@ -54,6 +54,7 @@ struct Layer {
   // LDS images of the stream kernels (ita_stream_kernel.h), device copies: whole layer, whole layer with the
   // tokenizer in front (layer 0 of the E = 64 model), attention block only
   char *simg_enc = nullptr, *simg_tok = nullptr, *simg_mha = nullptr;
+  unsigned fast_sites = 0;   // ITA_SITE_* bits: requantisation sites proven equal under single rounding (fast_site_ok)
 };
 
 }  // namespace
@@ -367,18 +368,60 @@ int build_stream_image(const StreamHostParams& p, char** d_out) {
 // The stream kernels read an int32 accumulator as the float 1.5 * 2^23 + sum, which is exact while |sum| < 2^22.
 // Worst case of a Linear row: sum_k |w| * 128 + |bias| (inputs are int8 codes).  QK^T (192 * 128 * 128) and A.V
 // (<= 255 * 128) are inside the range by construction.  A blob outside it runs on the block kernels instead.
-bool stream_range_ok(const StreamHostParams& p, int E, bool ffn) {
-  auto rows_ok = [](const int8_t* w, const int32_t* b, int rows, int k) {
+bool stream_range_ok(const StreamHostParams& p, int E, bool ffn, const float* ascal, const float* fscal) {
+  // ... and the requantised value travels as a 16-bit integer between the rounding and the u8 saturation
+  // (ita_device.h: rq_pack16_v3), so |acc * mult| + 128 has to stay below 2^15 as well: same worst case times the multiplier.
+  auto rows_ok = [](const int8_t* w, const int32_t* b, int rows, int k, float mult) {
+    if (!(mult > 0.0f)) return false;
     for (int r = 0; r < rows; ++r) {
       long long sum = 0;
       for (int i = 0; i < k; ++i) sum += w[(size_t)r * k + i] < 0 ? -(long long)w[(size_t)r * k + i] : w[(size_t)r * k + i];
       const long long bb = b[r] < 0 ? -(long long)b[r] : b[r];
       if (sum * 128 + bb >= (1ll << 22)) return false;
+      if ((double)(sum * 128 + bb) * (double)mult >= 32000.0) return false;
     }
     return true;
   };
-  return rows_ok(p.wq, p.bq, 192, E) && rows_ok(p.wk, p.bk, 192, E) && rows_ok(p.wv, p.bv, 192, E) &&
-         rows_ok(p.wo, p.bo, E, 192) && (!ffn || (rows_ok(p.w1, p.b1, 256, E) && rows_ok(p.w2, p.b2, E, 256)));
+  if (!(ascal[ITA_A_ML] > 0.0f) || 192.0 * 128 * 128 * (double)ascal[ITA_A_ML] >= 32000.0) return false;   // Q K^T
+  // A V: the integer softmax's probabilities sum to at most 255 per row (each is floor(num * 255 / sum(num))), so |sum p v| <= 255 * 128
+  if (!(ascal[ITA_A_MC] > 0.0f) || 255.0 * 128 * (double)ascal[ITA_A_MC] >= 32000.0) return false;
+  return rows_ok(p.wq, p.bq, 192, E, ascal[ITA_A_MQ]) && rows_ok(p.wk, p.bk, 192, E, ascal[ITA_A_MK]) &&
+         rows_ok(p.wv, p.bv, 192, E, ascal[ITA_A_MV]) && rows_ok(p.wo, p.bo, E, 192, ascal[ITA_A_MO]) &&
+         (!ffn || (rows_ok(p.w1, p.b1, 256, E, fscal[ITA_F_M1]) && rows_ok(p.w2, p.b2, E, 256, fscal[ITA_F_M2])));
+}
+
+// Single-rounding permission of one requantisation site.  The reference computes rne(fl(acc * m)) -- two roundings; the
+// fast form of the stream kernels computes fl(acc * m + magic) in one fused multiply-add -- one rounding.  They can differ
+// only for an accumulator value whose exact product lies within half an ulp of a rounding tie without being one.  The set of
+// accumulator values that matter is small (|acc * m| below the clamp range: a few hundred thousand integers), so it is
+// simply enumerated, on the host, in the arithmetic the GPU instructions perform (IEEE f32 multiply, add and fma; this file
+// is compiled with -ffp-contract=off): a site is fast only if no value differs after the clamp.
+bool fast_site_ok(float m) {
+  if (!(m > 0.0f) || !(m < 1.0f)) return false;
+  const double lim = 130.0 / (double)m;
+  if (lim > 4.0e6) return false;   // outside the biased-float accumulator range: not a stream-kernel blob anyway
+  const long long A = (long long)lim + 2;
+  auto code = [](float t) {        // low 16 bits of the pattern = r + 128 (two's complement), then the u8 saturation
+    unsigned u;
+    memcpy(&u, &t, 4);
+    const int v = (int)(int16_t)(u & 0xffffu);
+    return v < 0 ? 0 : v > 255 ? 255 : v;
+  };
+  for (long long a = -A; a <= A; ++a) {
+    const float x = (float)a;
+    const float y = x * m;
+    if (code(y + ITA_MAGIC128_F) != code(fmaf(x, m, ITA_MAGIC128_F))) return false;
+  }
+  return true;
+}
+unsigned fast_sites_of(const float* ascal) {
+  static const char* env = getenv("ITA_FAST_SITES");   // diagnostic: force a mask (0 = the exact form everywhere)
+  if (env) return (unsigned)strtoul(env, nullptr, 0);
+  unsigned mask = 0;
+  const int idx[6] = {ITA_A_MQ, ITA_A_MK, ITA_A_MV, ITA_A_ML, ITA_A_MC, ITA_A_MO};
+  for (int i = 0; i < 6; ++i)
+    if (fast_site_ok(ascal[idx[i]])) mask |= 1u << i;   // bit order = ITA_SITE_Q, _K, _V, _L, _C, _O
+  return mask;
 }
 
 struct StreamIo {
@@ -407,32 +450,42 @@ int launch_stream(ita_context* c, int layer, int mode, bool fuse_ln, const Strea
   a.B = B; a.fuse_ln = fuse_ln ? 1 : 0;
   a.stamps = io.stamps; a.h0_src = io.h0_src; a.h0_dst = io.h0_dst; a.slots = io.slots;
   a.img = io.img; a.tok_tap = io.tok_tap; a.xq = io.xq; a.yq = io.yq;
+  a.fast_sites = L.fast_sites;
   const int grid = B < c->num_cus ? B : c->num_cus;
+  const bool fast = L.fast_sites == ITA_SITES_ALL;   // the single-rounding instantiation: all six sites proven (fast_site_ok)
+#define ITA_LAUNCH_STREAM(E_, FFN_, TOK_, IO8_)                                                                                   \
+  do {                                                                                                                            \
+    if (fast) hipLaunchKernelGGL((ita_stream_kernel<E_, FFN_, TOK_, false, IO8_, true>), dim3(grid), dim3(512),                     \
+                                 (ItaStreamLds<E_, FFN_, (TOK_) != 0>::TOTAL), s, a);                                              \
+    else hipLaunchKernelGGL((ita_stream_kernel<E_, FFN_, TOK_, false, IO8_, false>), dim3(grid), dim3(512),                         \
+                            (ItaStreamLds<E_, FFN_, (TOK_) != 0>::TOTAL), s, a);                                                   \
+  } while (0)
   if (mode == 2) {
     if (!L.simg_mha) return fail(ITA_ERR_UNSUPPORTED, "this layer has no attention image (accumulator range)");
     a.image = L.simg_mha;
-    if (c->hdr.E == 64) hipLaunchKernelGGL((ita_stream_kernel<64, false, 0, false, true>), dim3(grid), dim3(512), (ItaStreamLds<64, false, false>::TOTAL), s, a);
-    else hipLaunchKernelGGL((ita_stream_kernel<128, false, 0, false, true>), dim3(grid), dim3(512), (ItaStreamLds<128, false, false>::TOTAL), s, a);
+    if (c->hdr.E == 64) ITA_LAUNCH_STREAM(64, false, 0, true);
+    else ITA_LAUNCH_STREAM(128, false, 0, true);
   } else if (mode == 1) {
     if (!L.simg_mha) return fail(ITA_ERR_BAD_BLOB, "attention image missing");
     if (fuse_ln && !L.n1w) return fail(ITA_ERR_BAD_BLOB, "norm1 parameters missing from the blob");
     a.image = L.simg_mha;
-    if (c->hdr.E == 64) hipLaunchKernelGGL((ita_stream_kernel<64, false, 0>), dim3(grid), dim3(512), (ItaStreamLds<64, false, false>::TOTAL), s, a);
-    else hipLaunchKernelGGL((ita_stream_kernel<128, false, 0>), dim3(grid), dim3(512), (ItaStreamLds<128, false, false>::TOTAL), s, a);
+    if (c->hdr.E == 64) ITA_LAUNCH_STREAM(64, false, 0, false);
+    else ITA_LAUNCH_STREAM(128, false, 0, false);
   } else if (io.img) {
     if (!L.simg_tok) return fail(ITA_ERR_BAD_BLOB, "tokenizer / LayerNorm parameters missing from the blob");
     a.image = L.simg_tok;
     if (io.stamps) hipLaunchKernelGGL((ita_stream_kernel<64, true, 1, true>), dim3(grid), dim3(512), (ItaStreamLds<64, true, true>::TOTAL), s, a);
-    else hipLaunchKernelGGL((ita_stream_kernel<64, true, 1>), dim3(grid), dim3(512), (ItaStreamLds<64, true, true>::TOTAL), s, a);
+    else ITA_LAUNCH_STREAM(64, true, 1, false);
   } else {
     if (!L.simg_enc) return fail(ITA_ERR_BAD_BLOB, "LayerNorm parameters missing from the blob");
     a.image = L.simg_enc;
     if (c->hdr.E == 128) {   // attention + FFN of an E = 128 layer in one launch; fc1 / fc2 weights are read from the global image
       if (io.stamps) return fail(ITA_ERR_UNSUPPORTED, "phase stamps are built for the E = 64 encoder");
-      hipLaunchKernelGGL((ita_stream_kernel<128, true, 0>), dim3(grid), dim3(512), (ItaStreamLds<128, true, false>::TOTAL), s, a);
+      ITA_LAUNCH_STREAM(128, true, 0, false);
     } else if (io.stamps) hipLaunchKernelGGL((ita_stream_kernel<64, true, 0, true>), dim3(grid), dim3(512), (ItaStreamLds<64, true, false>::TOTAL), s, a);
-    else hipLaunchKernelGGL((ita_stream_kernel<64, true, 0>), dim3(grid), dim3(512), (ItaStreamLds<64, true, false>::TOTAL), s, a);
+    else ITA_LAUNCH_STREAM(64, true, 0, false);
   }
+#undef ITA_LAUNCH_STREAM
   HIPCHK(hipGetLastError());
   return ITA_OK;
 }
@@ -751,6 +804,13 @@ int ita_create(ita_handle* out, int device_ordinal) {
   if ((rc = set_lds(ita_tokenizer_kernel<128, true>, ita_tok_lds_bytes<128>()))) { delete c; return rc; }
   if ((rc = set_lds(ita_tokenizer_kernel<128, false>, ita_tok_lds_bytes<128>()))) { delete c; return rc; }
   if ((rc = set_lds(ita_tail_kernel<64>, ita_tail_lds_bytes<64>()))) { delete c; return rc; }
+  if ((rc = set_lds(ita_stream_kernel<64, true, 1, false, false, true>, ItaStreamLds<64, true, true>::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_stream_kernel<64, true, 0, false, false, true>, ItaStreamLds<64, true, false>::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_stream_kernel<64, false, 0, false, false, true>, ItaStreamLds<64, false, false>::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_stream_kernel<128, false, 0, false, false, true>, ItaStreamLds<128, false, false>::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_stream_kernel<128, true, 0, false, false, true>, ItaStreamLds<128, true, false>::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_stream_kernel<64, false, 0, false, true, true>, ItaStreamLds<64, false, false>::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_stream_kernel<128, false, 0, false, true, true>, ItaStreamLds<128, false, false>::TOTAL))) { delete c; return rc; }
   if ((rc = set_lds(ita_stream_kernel<64, true, 1>, ItaStreamLds<64, true, true>::TOTAL))) { delete c; return rc; }
   if ((rc = set_lds(ita_stream_kernel<64, true, 0>, ItaStreamLds<64, true, false>::TOTAL))) { delete c; return rc; }
   if ((rc = set_lds(ita_stream_kernel<64, true, 1, true>, ItaStreamLds<64, true, true>::TOTAL))) { delete c; return rc; }
@@ -873,8 +933,9 @@ int ita_load_weights(ita_handle h, const void* blob, size_t nbytes) {
     sp.tlw = hptr<float>(h, "tok.ln_w"); sp.tlb = hptr<float>(h, "tok.ln_b");
     sp.conv_w = hptr<float>(h, "tok.conv_w"); sp.conv_b = hptr<float>(h, "tok.conv_b");
     int rc2 = ITA_OK;
-    const bool lns = sp.n1w && sp.n1b && sp.n2w && sp.n2b && stream_range_ok(sp, hdr.E, true);
-    if (!stream_range_ok(sp, hdr.E, false)) continue;   // no images: this layer runs on the block kernels
+    const bool lns = sp.n1w && sp.n1b && sp.n2w && sp.n2b && stream_range_ok(sp, hdr.E, true, L.ascal, L.fscal);
+    if (!stream_range_ok(sp, hdr.E, false, L.ascal, L.fscal)) continue;   // no images: this layer runs on the block kernels
+    L.fast_sites = fast_sites_of(L.ascal);
     if (hdr.E == 64) {
       rc2 = build_stream_image<64, false, false>(sp, &L.simg_mha);
       if (!rc2 && lns) rc2 = build_stream_image<64, true, false>(sp, &L.simg_enc);

@@ -54,7 +54,12 @@ struct ItaStreamArgs {
   int8_t* yq;             // (B,128,E) out_proj codes (no dequantisation, no residual)
   const void* img;        // (B,60,90) u8 wire frames (TOK == 1)
   float* tok_tap;         // optional (B,128,E): the tokens
+  // bit s set: requantisation site s may use the single-rounding form (one v_pk_fma_f32 instead of multiply + magic add):
+  // ita_load_weights has enumerated every accumulator value of the site's clamp range and found the two forms equal.
+  // Informational inside the kernel: the launcher picks the FAST instantiation when all six bits are set.
+  unsigned fast_sites;
 };
+enum { ITA_SITE_Q = 1, ITA_SITE_K = 2, ITA_SITE_V = 4, ITA_SITE_L = 8, ITA_SITE_C = 16, ITA_SITE_O = 32, ITA_SITES_ALL = 63 };
 
 #ifdef ITA_NO_SCHEDBAR
 #define ITA_SCHED_BARRIER() do {} while (0)
@@ -170,20 +175,25 @@ __device__ __forceinline__ void layernorm_q16(float (&r)[E / 4], const float* w,
 // probabilities ride a signed MFMA as p - 128; the 128 * colsum(V) term restores them).
 typedef short ita_s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short ita_u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void ita_softmax_packed16(const ita_s16x2 (&w)[16], i32x4 (&pf)[2]) {
-  typedef ita_s16x2 s16x2;
+// The logits arrive UNCLAMPED and biased, u = rne(acc * m) + 32768 (order-preserving u16, lg8_v3); the reference's clamp to
+// [-128, 127] happens here at no cost:  m' = clamp(max, -128, 127);  shift = m' - clamp(x)  =  min(max(m' - x, 0), m' + 128)
+// -- the saturating unsigned subtraction is the max(., 0) (x above the clamped maximum), and the row-wise cap
+// min(m' + 128, 15) covers both x below -128 and the 15 beyond which every shift gives 0.
+__device__ __forceinline__ void ita_softmax_packed16(const ita_u16x2 (&w)[16], i32x4 (&pf)[2]) {
   typedef ita_u16x2 u16x2;
-  s16x2 m2 = w[0];
+  u16x2 m2 = w[0];
 #pragma unroll
   for (int j = 1; j < 16; ++j) m2 = __builtin_elementwise_max(m2, w[j]);
-  const int m = max1632_i(max((int)m2.x, (int)m2.y));
-  const s16x2 mm = {(short)m, (short)m};
-  const s16x2 cap = {15, 15};                  // 256 >> s and inv_hi >> s are both 0 from s = 9 on
+  int m = max1632_i(max((int)m2.x, (int)m2.y));
+  m = min(max(m, 32768 - 128), 32768 + 127);
+  const u16x2 mm = {(unsigned short)m, (unsigned short)m};
+  const unsigned short capv = (unsigned short)min(m - (32768 - 128), 15);   // 256 >> s and inv_hi >> s are both 0 from s = 9 on
+  const u16x2 cap = {capv, capv};
   const u16x2 one = {256, 256};
   u16x2 sh[16], sum2 = {0, 0};
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    sh[j] = __builtin_bit_cast(u16x2, __builtin_elementwise_min((s16x2)(mm - w[j]), cap));
+    sh[j] = __builtin_elementwise_min(__builtin_elementwise_sub_sat(mm, w[j]), cap);
     sum2 += one >> sh[j];
   }
   int sum = sum1632_i((int)sum2.x + (int)sum2.y);   // <= 16 * 256 per half: no 16-bit overflow
@@ -207,12 +217,12 @@ __device__ __forceinline__ void ita_softmax_packed16(const ita_s16x2 (&w)[16], i
 __global__ __launch_bounds__(64) void ita_softmax_rows_kernel(const int8_t* __restrict__ logits, uint8_t* __restrict__ probs, int rows) {
   const int lane = threadIdx.x, qi = lane & 15, kq = lane >> 4;
   const int row = min((int)blockIdx.x * 16 + qi, rows - 1);
-  ita_s16x2 w[16];
+  ita_u16x2 w[16];
 #pragma unroll
   for (int kt = 0; kt < 8; ++kt) {
     const int v = *(const int*)(logits + (size_t)row * 128 + 16 * kt + 4 * kq);
-    w[2 * kt] = (ita_s16x2){(short)(int8_t)v, (short)(int8_t)(v >> 8)};
-    w[2 * kt + 1] = (ita_s16x2){(short)(int8_t)(v >> 16), (short)(int8_t)(v >> 24)};
+    w[2 * kt] = (ita_u16x2){(unsigned short)((int)(int8_t)v + 32768), (unsigned short)((int)(int8_t)(v >> 8) + 32768)};
+    w[2 * kt + 1] = (ita_u16x2){(unsigned short)((int)(int8_t)(v >> 16) + 32768), (unsigned short)((int)(int8_t)(v >> 24) + 32768)};
   }
   i32x4 pf[2];
   ita_softmax_packed16(w, pf);
@@ -282,13 +292,20 @@ __device__ __forceinline__ void mm_group(const ItaFr<4 * NKS>& f, const i32x4 (&
     for (int ks = 0; ks < NKS; ++ks)
       acc[t] = SWAP ? mfma16(x[ks], f.w[t * NKS + ks], acc[t]) : mfma16(f.w[t * NKS + ks], x[ks], acc[t]);
 }
-// requantise four tiles and pack them: ONE B fragment of the next GEMM (byte 4t+i <-> row 4kq+i of tile t)
-__device__ __forceinline__ i32x4 rq_group(const i32x4 (&acc)[4], float mult, float lo) {
+// requantise four tiles and pack them: ONE B fragment of the next GEMM (byte 4t+i <-> row 4kq+i of tile t).
+// fast (wave-uniform): this site's multiplier passed the load-time single-rounding proof (ita_device.h: rq_pack16_v3);
+// RELU: fc1, clamp to [0, 127].  -DITA_RQ_STYLE=2 keeps the round-2 form (float clamp, 3.0 instructions per value).
+template <bool RELU = false>
+__device__ __forceinline__ i32x4 rq_group(const i32x4 (&acc)[4], float mult, bool fast) {
   if constexpr (ITA_ABLATE & 1) return acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
 #if defined(ITA_RQ_STYLE) && ITA_RQ_STYLE == 1
-  return rq_pack16_c(acc, mult, lo);
+  return rq_pack16_c(acc, mult, RELU ? 0.0f : -128.0f);
+#elif defined(ITA_RQ_STYLE) && ITA_RQ_STYLE == 2
+  return rq_pack16_b(acc, mult, RELU ? 0.0f : -128.0f);
 #else
-  return rq_pack16_b(acc, mult, lo);
+  if constexpr (RELU) return rq_pack16_v3<ITA_RQ_RELU>(acc, mult);
+  if (fast) return rq_pack16_v3<ITA_RQ_FAST>(acc, mult);
+  return rq_pack16_v3<ITA_RQ_EXACT>(acc, mult);
 #endif
 }
 // block output: d[4t+i] = dequantised int8 code of channel (E/4)kq + 4(et0+t) + i
@@ -356,7 +373,11 @@ __device__ __forceinline__ void st_tok_quarter(float* row, int kq, const float (
 
 // (amdgpu_waves_per_eu(2, 2): the workgroup owns the CU's LDS, so two waves per SIMD is all there will ever be -- without
 // it the scheduler trades instruction-level parallelism for registers it has no use for: the LDS size is dynamic)
-template <int E, bool FFN, int TOK, bool STAMP = false, bool IO8 = false>
+// FAST: every requantisation site of this layer passed the load-time single-rounding proof (ita_plugin.hip: fast_site_ok).
+// A compile-time switch, two instantiations: as a run-time flag per site the two forms sit side by side in the frame loop
+// and the ~40 uniform branches per frame cost more than the shorter form saves (measured: 56.7 us against 56.5 for the
+// round-2 form, 54.0 with the fast form compiled in, 55.3 with the exact one).
+template <int E, bool FFN, int TOK, bool STAMP = false, bool IO8 = false, bool FAST = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void ita_stream_kernel(const ItaStreamArgs a) {
   static_assert(!IO8 || (!FFN && TOK == 0), "int8 I/O is the attention block's form");
   using L = ItaStreamLds<E, FFN, TOK != 0>;
@@ -371,6 +392,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             *l_b2 = bias + 3 * P + E + F;
   const float* lnp = (const float*)(lds + L::LNP);
   int* colsum = (int*)(lds + L::COLSUM);
+  // per-site single-rounding permission (ItaStreamArgs::fast_sites, proven at load time): wave-uniform scalars
+  auto site_fast = [&](unsigned bit) {
+#ifdef ITA_FORCE_SITES   // counting builds (tools/valu_budget.py): one form per site at compile time
+    return ((unsigned)(ITA_FORCE_SITES) & bit) != 0;
+#endif
+    (void)bit;
+    return FAST;
+  };
+#define fq site_fast(ITA_SITE_Q)
+#define fk site_fast(ITA_SITE_K)
+#define fv site_fast(ITA_SITE_V)
+#define fl site_fast(ITA_SITE_L)
+#define fc site_fast(ITA_SITE_C)
+#define fo site_fast(ITA_SITE_O)
 
   // waves 4-7 were dispatched second and lose every VALU arbitration against their SIMD partner (MI355X guide,
   // "Two waves per SIMD", item 4): static priority evens the pair out
@@ -573,7 +608,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // side copy of the LSTM layer-0 state row (see ItaStreamArgs): the row was requested a phase ago -- a load waited
     // for here would hold wave 0, and with it the whole workgroup's next barrier, for a full memory latency
     if (!(ITA_ABLATE & 128) && a.h0_dst && tid < 32) {
-      *(f32x4*)(a.h0_dst + (size_t)b * 128 + 4 * tid) = h0_cur;
+      *(f32x4*)(a.h0_dst + (size_t)b * 128 + 4 * ol) = h0_cur;   // (tid < 32: tid == ol; the opaque copy keeps the address out of the loop-invariant set)
       if (nb < a.B) h0_row_next = a.slots ? a.slots[nb] : nb;
     }
 
@@ -592,13 +627,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       auto epilogue = [&](int g, const i32x4 (&acc)[4]) {
         const int mat = g / 3, gg = g - 3 * mat;
         if (mat == 0) {
-          qf[gg] = rq_group(acc, a.mq, -128.0f);
+          qf[gg] = rq_group(acc, a.mq, fq);
         } else if (mat == 1) {
-          *(i32x4*)(lds + L::K + (((4 * gg + kq) * S + token) << 4)) = rq_group(acc, a.mk, -128.0f);
+          *(i32x4*)(lds + L::K + (((4 * gg + kq) * S + token) << 4)) = rq_group(acc, a.mk, fk);
         } else {
           // V with the roles swapped (A = tokens, B = weights): lane (feature qi, kq) holds keys 16w + 4kq + i of
           // feature 16 dt + qi -- one dword of the V^T slot (key block w>>2, k-group kq), at word w&3
-          const i32x4 p4 = rq_group(acc, a.mv, -128.0f);
+          const i32x4 p4 = rq_group(acc, a.mv, fv);
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const int d = (4 * gg + t) * 16 + qi;
@@ -626,7 +661,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // next frame's input: issued now, consumed after the attention phase
     if (!(ITA_ABLATE & 128) && a.h0_dst && tid < 32 && nb < a.B)
-      h0_cur = *(const f32x4*)(a.h0_src + (size_t)h0_row_next * 128 + 4 * tid);
+      h0_cur = *(const f32x4*)(a.h0_src + (size_t)h0_row_next * 128 + 4 * ol);
     float xn[EC];
     i32x4 xq_nxt[NK];
     if constexpr (TOK != 0) {
@@ -647,8 +682,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     {
       // logits as packed signed 16-bit pairs: the integer softmax then runs on v_pk_*_16, two keys per
       // VALU op.  w[2kt + j] = {logit 4kt+2j, logit 4kt+2j+1} of keys 16kt + 4kq + ...
-      typedef ita_s16x2 s16x2;
-      s16x2 w[16];
+      typedef ita_u16x2 u16x2;
+      u16x2 w[16];
       struct KFr { i32x4 w[6]; } kfr[2];   // two key tiles x three k-steps
       ItaF4 vb[2];
       i32x4 va[3][4];
@@ -678,18 +713,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
       };
       auto epil = [&](int p, const i32x4 (&acc)[2]) {
-        unsigned bi[8];
-#if defined(ITA_RQ_STYLE) && ITA_RQ_STYLE == 1
-        lg8_c(acc, a.ml, bi);
-#else
-        lg8_b(acc, a.ml, bi);   // low 16 bits = rne(logit), two's complement
-#endif
+        // low 16 bits = rne(logit) + 32768, unclamped: the softmax clamps (ita_softmax_packed16)
+        unsigned w4[4];
+        if (fl) lg8_v3<ITA_RQ_FAST>(acc, a.ml, w4);
+        else lg8_v3<ITA_RQ_EXACT>(acc, a.ml, w4);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-            w[2 * (2 * p + t) + j] =
-                __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(bi[4 * t + 2 * j + 1], bi[4 * t + 2 * j], 0x05040100u));
+          for (int j = 0; j < 2; ++j) w[2 * (2 * p + t) + j] = __builtin_bit_cast(u16x2, w4[2 * t + j]);
       };
       ldk(0, kfr[0]);
 #pragma unroll
@@ -717,7 +748,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int st = 0; st < 6; ++st) {
         if (st + 1 < 6) ldv(st + 1, vb[(st + 1) & 1]);
         mm_ks(vb[st & 1], pf[st & 1], va[st >> 1]);
-        if (st == 3) cf[0] = rq_group(va[0], a.mc, -128.0f);
+        if (st == 3) cf[0] = rq_group(va[0], a.mc, fc);
         ITA_SCHED_BARRIER();   // keep the step's loads ahead of the next step's MFMAs
       }
       ITA_SSTAMP(5);
@@ -728,10 +759,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       ld_obias<E>(oa, l_bo, 0, kq);
       // the next frame's pixel window, before this frame's global stores (one in-order vmcnt for loads and stores)
       if constexpr (TOK != 0) { if (more) tok_fill(ol); }
-      cf[1] = rq_group(va[1], a.mc, -128.0f);
+      cf[1] = rq_group(va[1], a.mc, fc);
       ld_frg_ks<E>(ob[1], lds + L::WO, 0, 1, qi, kq);
       mm_ks(ob[0], cf[0], oa);
-      cf[2] = rq_group(va[2], a.mc, -128.0f);
+      cf[2] = rq_group(va[2], a.mc, fc);
     }
     if constexpr (TOK != 0 && !(ITA_ABLATE & 4)) { if (more) tok_blend(ol); }
 
@@ -756,7 +787,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
       if constexpr (TOK != 0 && ITA_TOK_MID && !(ITA_ABLATE & 4)) { if (more) { tok_step(0, ol); tok_step(1, ol); } }
       if constexpr (IO8) {   // the int8 codes themselves: 16 channels of this lane's token, one 16-byte store
-        *(i32x4*)(a.yq + ((size_t)b * S + token) * E + EC * kq + 16 * eg) = rq_group(oa, a.mo, -128.0f);
+        *(i32x4*)(a.yq + ((size_t)b * S + token) * E + EC * kq + 16 * eg) = rq_group(oa, a.mo, fo);
         if (eg + 1 < EG) ld_obias<E>(oa, l_bo, 4 * (eg + 1), kq);
         continue;
       }
@@ -801,12 +832,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         mm_group<NK, false>(ffr[g & 1], x1f, fa[g % 3]);
         if (g >= 2) mm_ks(wb[(g - 2) & 1], hf[g - 2], ya);
         if constexpr (TOK != 0 && ITA_TOK_MID && !(ITA_ABLATE & 4)) { if (more) { tok_step(4 + 2 * g, ol); tok_step(5 + 2 * g, ol); } }
-        if (g >= 1) hf[g - 1] = rq_group(fa[(g - 1) % 3], a.m1, 0.0f);
+        if (g >= 1) hf[g - 1] = rq_group<true>(fa[(g - 1) % 3], a.m1, false);
         ITA_SCHED_BARRIER();   // keep the step's loads ahead of the next step's MFMAs
       }
       ld_frg_ks<E>(wb[1], w2p, 0, 3, qi, kq);
       mm_ks(wb[0], hf[2], ya);
-      hf[3] = rq_group(fa[3 % 3], a.m1, 0.0f);
+      hf[3] = rq_group<true>(fa[3 % 3], a.m1, false);
       mm_ks(wb[1], hf[3], ya);
       if constexpr (TOK != 0 && ITA_TOK_MID && !(ITA_ABLATE & 4)) { if (more) tok_step(12, ol); }
       ITA_SSTAMP(8);
@@ -879,6 +910,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (STAMP && a.stamps && (tid & 255) == 0)
     a.stamps[(((size_t)blockIdx.x * 8) * 2 + (wave >> 2)) * 16 + 14] = __builtin_amdgcn_s_memrealtime();
 #undef ITA_SSTAMP
+#undef fq
+#undef fk
+#undef fv
+#undef fl
+#undef fc
+#undef fo
 }
 
 // ------------------------------------------------------------------ the tokenizer on its own

@@ -151,6 +151,15 @@ def test_graphed_step_equals_eager_forward():
             ve, st = eng.forward(img, dv, qt, st)
             assert torch.equal(vg, ve), (B, t)
             assert torch.equal(g.h, st[0]) and torch.equal(g.c, st[1])
+        if B == 1:
+            # a larger graph would reallocate the workspace this one's captured kernels point into: refused while it lives
+            with pytest.raises(host.ITAError, match="live captured graph"):
+                eng.graphed_step(5)
+        del g
+    with pytest.raises(host.ITAError):
+        eng.pipelined_steps(4, n_steps=1)
+    with pytest.raises(host.ITAError):
+        eng.pipelined_steps(4, n_steps=8, stages=4)
     eng.close()
 
 

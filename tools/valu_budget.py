@@ -2,19 +2,22 @@
 """Counted instruction budget of the encoder kernel's frame loop, from the ISA hipcc emits for gfx950 (no GPU needed).
 Compiles csrc/ita_plugin.hip to assembly, takes ita_stream_kernel<64, true, 1> from its frame-loop header to the end of the
 function (the loop body; inline-asm requantisation blocks are expanded in the assembly) and groups the opcodes.
-Counts are per WAVE and frame; a frame is 8 waves.  usage: python tools/valu_budget.py"""
+Counts are per WAVE and frame; a frame is 8 waves.  usage: python tools/valu_budget.py [extra hipcc flags]
+The single-rounding permission of a requantisation site is a run-time flag (both forms are in the code): count one form with
+-DITA_FORCE_SITES=0 (exact everywhere) or -DITA_FORCE_SITES=63 (fast everywhere); -DITA_RQ_STYLE=2 is the round-2 form."""
 import collections, os, re, subprocess, sys, tempfile
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, "drone-oa-iree-vit-accelerator_amd", "csrc", "ita_plugin.hip")
 KERNEL = "_Z17ita_stream_kernelILi64ELb1ELi1ELb0ELb0EEv13ItaStreamArgs"
 CLASSES = [
-    ("requantise: unbias + scale (v_pk_add/mul_f32)", r"^v_pk_(add|mul)_f32"),
-    ("requantise: clamp (v_med3_f32)", r"^v_med3_f32"),
+    ("requantise: unbias + scale + round (v_pk_add/mul/fma_f32, v_pk_mov)", r"^v_pk_(add|mul|fma)_f32|^v_pk_mov"),
+    ("requantise: float clamp (v_med3_f32)", r"^v_med3_f32"),
     ("requantise: round + byte insert (SDWA add)", r"^v_add_f32_sdwa"),
+    ("requantise: 16-bit pairs, u8 saturation, sign flip (v_perm, v_sat_pk, v_xor)", r"^v_perm_b32|^v_sat_pk_u8_i16|^v_xor_b32"),
     ("integer softmax (packed 16-bit)", r"^v_pk_.*(i16|u16|b16)|^v_dot4|^v_rndne|^v_permlane|^v_cndmask"),
-    ("float: LayerNorm, residuals, dequantise, f16 split", r"^v_(add|sub|mul|fma|fmac|rcp|rsq|sqrt|div|pk_fma|cvt_pk_f16|cvt_f16|cvt_f32_f16|max|min)_?"),
-    ("tokenizer blend / window (integer)", r"^v_(mul_u32_u24|mad_u32_u24|alignbyte|alignbit|cvt_f32_u32|bfe|and_b32|or_b32|lshl|lshr|add_u32|add3|lshl_add|perm)"),
+    ("float: LayerNorm, residuals, dequantise, f16 split", r"^v_(add|sub|mul|fma|fmac|rcp|rsq|sqrt|div|cvt_pk_f16|cvt_f16|cvt_f32_f16|max|min)_?"),
+    ("tokenizer blend / window (integer)", r"^v_(mul_u32_u24|mad_u32_u24|alignbyte|alignbit|cvt_f32_u32|bfe|and_b32|or_b32|lshl|lshr|add_u32|add3|lshl_add)"),
     ("moves", r"^v_mov|^v_accvgpr|^v_readfirstlane"),
 ]
 
@@ -23,7 +26,7 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I",
-                               os.path.join(REPO, "include"), "--cuda-device-only", "-S", "-o", out, SRC],
+                               os.path.join(REPO, "include"), "--cuda-device-only", "-S", "-o", out, SRC] + sys.argv[1:],
                               stderr=subprocess.DEVNULL)
         lines = open(out).read().split("\n")
     beg = next(i for i, l in enumerate(lines) if l.startswith(KERNEL + ":"))
