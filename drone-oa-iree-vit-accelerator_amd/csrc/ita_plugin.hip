@@ -302,6 +302,49 @@ struct StreamHostParams {
   const float *n1w, *n1b, *n2w, *n2b, *tlw, *tlb, *conv_w, *conv_b;
 };
 
+// The integer conv tables of the u8 tokenizer (ita_stream_kernel.h: ItaTokTab; definition: oracle/ita_oracle.c
+// ita_oracle_tok_quant_weights / ita_oracle_tokenizer_u8): per channel 23-bit fixed-point weights Wq = rne(w * 2^e), e = 22 -
+// exponent(max |w|), split into balanced bytes w0, w1 and the remainder w2, laid out as int8 MFMA A fragments.
+template <int E>
+void build_tok_tab(const float* conv_w, const float* conv_b, char* tab) {
+  using T = ItaTokTab<E>;
+  int32_t* ti = (int32_t*)(tab + T::TI);
+  float* ts = (float*)(tab + T::TS);
+  std::vector<int8_t> dig((size_t)E * 49 * 3);
+  for (int c = 0; c < E; ++c) {
+    float mx = 0.0f;
+    for (int k = 0; k < 49; ++k) mx = fmaxf(mx, fabsf(conv_w[(size_t)c * 49 + k]));
+    int e = 0;
+    if (mx > 0.0f) {
+      int ex;
+      (void)frexpf(mx, &ex);
+      e = 22 - ex;
+    }
+    long long s0 = 0, s1 = 0, s2 = 0;
+    for (int k = 0; k < 49; ++k) {
+      const int32_t W = (int32_t)rintf(ldexpf(conv_w[(size_t)c * 49 + k], e));
+      const int32_t w0 = ((W + 128) & 255) - 128, W1r = (W - w0) >> 8;
+      const int32_t w1 = ((W1r + 128) & 255) - 128, w2 = (W1r - w1) >> 8;
+      dig[((size_t)c * 49 + k) * 3 + 0] = (int8_t)w0; dig[((size_t)c * 49 + k) * 3 + 1] = (int8_t)w1; dig[((size_t)c * 49 + k) * 3 + 2] = (int8_t)w2;
+      s0 += w0; s1 += w1; s2 += w2;
+    }
+    // the kernel feeds a ^ 0x80 = a - 128: S0 = S0' + 128 sum w0, S1 = S1' + 128 (sum w1 + sum w0), ... (L = S0 + 256 S1, H = S2 + 256 S3)
+    ti[c] = (int32_t)(128 * s0 + 256 * 128 * (s1 + s0));
+    ti[E + c] = (int32_t)(128 * (s2 + s1) + 256 * 128 * s2);
+    const float sc = ldexpf(1.0f, -e) / 65280.0f;
+    ts[c] = sc; ts[E + c] = 65536.0f * sc; ts[2 * E + c] = conv_b[c];
+  }
+  for (int ct = 0; ct < T::NCT; ++ct)
+    for (int j = 0; j < 3; ++j)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int rho = lane & 15, kq = lane >> 4, ch = (E / 4) * (rho >> 2) + 4 * ct + (rho & 3);
+        for (int b = 0; b < 16; ++b) {
+          const int t = 4 * b + kq;        // slot b of k-group kq <-> tap 4 b + kq (the lane that blends it); taps >= 49: zero
+          tab[T::TW + ((ct * 3 + j) * 64 + lane) * 16 + b] = t < 49 ? (char)dig[((size_t)ch * 49 + t) * 3 + j] : 0;
+        }
+      }
+}
+
 template <int E, bool FFN, bool TOK>
 int build_stream_image(const StreamHostParams& p, char** d_out) {
   using L = ItaStreamLds<E, FFN, TOK>;
@@ -341,16 +384,7 @@ int build_stream_image(const StreamHostParams& p, char** d_out) {
   }
   if constexpr (TOK) {
     memcpy(ln + 4 * E, p.tlw, E * 4); memcpy(ln + 5 * E, p.tlb, E * 4);
-    // A fragments of v_mfma_f32_16x16x4_f32: lane (rho = lane & 15, k = lane >> 4) of step s, channel tile ct
-    float* cw = (float*)(im.data() + L::CW);
-    for (int s = 0; s < 13; ++s)
-      for (int ct = 0; ct < 4; ++ct)
-        for (int lane = 0; lane < 64; ++lane) {
-          const int t = 4 * s + (lane >> 4), rho = lane & 15, ch = 16 * (rho >> 2) + 4 * ct + (rho & 3);
-          // scaled by 1 / (255 * 256): the kernel's blend is the exact integer 65280 * (patch value) on pixel codes
-          cw[(s * 4 + ct) * 64 + lane] = t < 49 ? p.conv_w[(size_t)ch * 49 + t] * (1.0f / 65280.0f) : 0.0f;
-        }
-    memcpy(im.data() + L::CB, p.conv_b, E * 4);
+    build_tok_tab<E>(p.conv_w, p.conv_b, im.data() + L::CW);
     int32_t* tap = (int32_t*)(im.data() + L::TAP);
     for (int t = 0; t < 52; ++t) tap[t] = t < 49 ? (t / 7) * 96 + (t % 7) : 0;
   }
@@ -534,8 +568,10 @@ int launch_tokenizer(ita_context* c, const void* img, int dtype, float* tokens, 
   if (!c->tok_w) return fail(ITA_ERR_BAD_BLOB, "tokenizer parameters missing from the blob");
   static const int tok_dbg = getenv("ITA_TOK_DBG") ? atoi(getenv("ITA_TOK_DBG")) : 0;
   const bool u8 = dtype == ITA_IMAGE_U8;
-  static const bool block_tok = getenv("ITA_TOK_BLOCK_KERNEL") != nullptr;   // diagnostic: the older tokenizer kernel for u8 frames too
-  if (c->tok_simg && !block_tok) {
+  // diagnostic: the older tokenizer kernel (f32 frames only: its u8 form predates the integer conv and is no longer the
+  // oracle's arithmetic; without a stream image -- E outside {64, 128} never loads -- u8 frames have no other path)
+  static const bool block_tok = getenv("ITA_TOK_BLOCK_KERNEL") != nullptr;
+  if (c->tok_simg && !(block_tok && !u8)) {
     ItaTokStreamArgs ta{c->tok_simg + (u8 ? 0 : c->tok_simg_bytes), img, tokens, B};
     const int g = B < c->num_cus ? B : c->num_cus;
     if (c->hdr.E == 64) {
@@ -548,7 +584,8 @@ int launch_tokenizer(ita_context* c, const void* img, int dtype, float* tokens, 
     HIPCHK(hipGetLastError());
     return ITA_OK;
   }
-  ItaTokArgs a{img, c->tok_wT + (u8 ? (size_t)50 * c->hdr.E : 0), c->tok_b, c->tok_lw, c->tok_lb, tokens, B, tok_dbg};
+  if (u8) return fail(ITA_ERR_UNSUPPORTED, "u8 frames need the stream tokenizer image");
+  ItaTokArgs a{img, c->tok_wT, c->tok_b, c->tok_lw, c->tok_lb, tokens, B, tok_dbg};
   const int grid = B < 2 * c->num_cus ? B : 2 * c->num_cus;
   if (c->hdr.E == 64) {
     if (u8) hipLaunchKernelGGL((ita_tokenizer_kernel<64, true>), dim3(grid), dim3(256), ita_tok_lds_bytes<64>(), s, a);
@@ -957,20 +994,32 @@ int ita_load_weights(ita_handle h, const void* blob, size_t nbytes) {
     HIPCHK(hipMalloc(&h->tok_wT, wT.size() * sizeof(float)));
     HIPCHK(hipMemcpy(h->tok_wT, wT.data(), wT.size() * sizeof(float), hipMemcpyHostToDevice));
     const float *cb = hptr<float>(h, "tok.conv_b"), *lw = hptr<float>(h, "tok.ln_w"), *lb = hptr<float>(h, "tok.ln_b");
-    if (cb && lw && lb && (Ei == 64 || Ei == 128)) {   // the LDS image of ita_tok_stream_kernel<E>
-      const int nct = Ei / 16, off_cw = 2 * Ei * 4, off_cb = off_cw + 13 * nct * 64 * 4, off_tap = off_cb + Ei * 4;
-      const size_t one = (size_t)off_tap + 52 * 4;
-      std::vector<char> im(2 * one, 0);      // [0]: u8 frames (weights x 1/65280: integer blend), [1]: f32 frames
-      for (int v = 0; v < 2; ++v) {
-        char* b0 = im.data() + v * one;
+    if (cb && lw && lb && (Ei == 64 || Ei == 128)) {   // the LDS images of ita_tok_stream_kernel<E, U8>
+      // [0]: u8 frames (integer conv tables), [1]: f32 frames (f32 MFMA A fragments); each padded to the larger of the two
+      const int nct = Ei / 16;
+      const size_t one8 = Ei == 64 ? (size_t)ItaTokStreamLds<64, true>::IMAGE : (size_t)ItaTokStreamLds<128, true>::IMAGE;
+      const size_t onef = Ei == 64 ? (size_t)ItaTokStreamLds<64, false>::IMAGE : (size_t)ItaTokStreamLds<128, false>::IMAGE;
+      const size_t one = ((one8 > onef ? one8 : onef) + 15) & ~(size_t)15;
+      std::vector<char> im(2 * one, 0);
+      {
+        char* b0 = im.data();
+        memcpy(b0, lw, Ei * 4); memcpy(b0 + Ei * 4, lb, Ei * 4);
+        int off_tap;
+        if (Ei == 64) { build_tok_tab<64>(cw, cb, b0 + ItaTokStreamLds<64, true>::CW); off_tap = ItaTokStreamLds<64, true>::TAP; }
+        else { build_tok_tab<128>(cw, cb, b0 + ItaTokStreamLds<128, true>::CW); off_tap = ItaTokStreamLds<128, true>::TAP; }
+        int32_t* tap = (int32_t*)(b0 + off_tap);
+        for (int t = 0; t < 52; ++t) tap[t] = t < 49 ? (t / 7) * 96 + (t % 7) : 0;
+      }
+      {
+        char* b0 = im.data() + one;
+        const int off_cw = 2 * Ei * 4, off_cb = off_cw + 13 * nct * 64 * 4, off_tap = off_cb + Ei * 4;
         memcpy(b0, lw, Ei * 4); memcpy(b0 + Ei * 4, lb, Ei * 4);
         float* cwf = (float*)(b0 + off_cw);
         for (int st = 0; st < 13; ++st)
           for (int ct = 0; ct < nct; ++ct)
             for (int lane = 0; lane < 64; ++lane) {
               const int t = 4 * st + (lane >> 4), rho = lane & 15, ch = (Ei / 4) * (rho >> 2) + 4 * ct + (rho & 3);
-              const float wv = t < 49 ? cw[(size_t)ch * 49 + t] : 0.0f;
-              cwf[(st * nct + ct) * 64 + lane] = v == 0 ? wv * (1.0f / 65280.0f) : wv;
+              cwf[(st * nct + ct) * 64 + lane] = t < 49 ? cw[(size_t)ch * 49 + t] : 0.0f;
             }
         memcpy(b0 + off_cb, cb, Ei * 4);
         int32_t* tap = (int32_t*)(b0 + off_tap);

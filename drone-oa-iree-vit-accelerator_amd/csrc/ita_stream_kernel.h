@@ -66,11 +66,88 @@ enum { ITA_SITE_Q = 1, ITA_SITE_K = 2, ITA_SITE_V = 4, ITA_SITE_L = 8, ITA_SITE_
 #else
 #define ITA_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #endif
-#ifdef ITA_TOK_AT_END   // experiment: all thirteen conv k-steps after the FFN instead of between its epilogues
-#define ITA_TOK_MID 0
-#else
-#define ITA_TOK_MID 1
+// Where the four conv tiles of the NEXT frame's tokenizer run inside a frame (each: six int8 MFMAs + 24 VALU + 8 LDS reads):
+//   0 (default) after LayerNorm2 and the output stores, where the kernel has registers to spare;
+//   1 spread over the out_proj / fc1 steps (needs ~20 more live registers at the kernel's tightest point: 7 spilled);
+//   2 all four right after the blend, in front of out_proj.
+// Measured on one box, encoder launch of 1024 frames: round-2 kernel 58.4 us, placement 0 with the blend at the end too
+// (ITA_TOK_BLEND_END, default) 52.1, placement 0 with the blend after B2 52.5, placement 2 52.9, placement 1 (another box) +1.5.
+#ifndef ITA_TOK_PLACE
+#define ITA_TOK_PLACE 0
 #endif
+#define ITA_TOK_MID (ITA_TOK_PLACE == 1)
+#ifndef ITA_TOK_BLEND_END   // placement 0 only: blend the taps at the end of the frame too (nothing of the tokenizer is then live across the FFN: 244 VGPRs)
+#define ITA_TOK_BLEND_END 1
+#endif
+
+// ---- the conv7x7 of the u8 tokenizer as int8 MFMA (oracle/ita_oracle.c: ita_oracle_tokenizer_u8).  The blended tap is the
+// exact integer B256 = 256 a1 + a0 <= 65280, the conv weight of a channel 23-bit fixed point Wq = 65536 w2 + 256 w1 + w0 with
+// balanced digits, and the 49-tap sum splits into byte products that int8 MFMAs accumulate exactly:
+//     S0 = sum a0 w0,  S1 = sum (a0 w1 + a1 w0),  S2 = sum (a0 w2 + a1 w1),  S3 = sum a1 w2,   L = S0 + 256 S1,  H = S2 + 256 S3
+//     pre = fma((float)H, 65536 s, fma((float)L, s, bias))
+// The unsigned bytes a0, a1 ride the signed MFMA as a ^ 0x80 = a - 128; the 128 * sum(w) terms sit in the accumulators'
+// initial values (I0 for S0 -- it also carries 256 x the term of S1 --, I2 for S2 / S3).  K = 64 slots of the 16x16x64 MFMA:
+// lane (token qi, k-group kq) holds its own 13 taps 4 j + kq in bytes j = 0..12 of its B fragment (the weight image has
+// the same slot -> tap mapping, zero weights in the three pad slots).  Six MFMAs per 16-channel tile instead of thirteen
+// v_mfma_f32_16x16x4_f32, which run at the f32 vector rate and hold the SIMD's VALU meanwhile (-5 us per 1024-frame launch).
+template <int E>
+struct ItaTokTab {
+  static constexpr int NCT = E / 16;
+  static constexpr int TW = 0;                          // int8 [NCT][3 byte planes][64 lanes][16]: A fragments, row rho <-> channel (E/4)(rho>>2) + 4 ct + (rho&3)
+  static constexpr int TI = TW + NCT * 3 * 1024;        // int32 [2][E]: I0 | I2
+  static constexpr int TS = TI + 2 * E * 4;             // f32 [3][E]: s | 65536 s | conv bias
+  static constexpr int BYTES = TS + 3 * E * 4;
+};
+// thirteen blended taps (exact integers) -> the two B fragments (low bytes, high bytes; both ^ 0x80)
+__device__ __forceinline__ void tok_u8_fragments(const unsigned (&pb)[13], i32x4& a0, i32x4& a1) {
+  unsigned p16[8];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) p16[k] = __builtin_amdgcn_perm(pb[2 * k + 1], pb[2 * k], 0x05040100u) ^ 0x80808080u;
+  p16[6] = (pb[12] & 0xffffu) ^ 0x80808080u;
+  p16[7] = 0;                                           // pad slots: their weights are zero
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    a0[d] = (int)__builtin_amdgcn_perm(p16[2 * d + 1], p16[2 * d], 0x06040200u);
+    a1[d] = (int)__builtin_amdgcn_perm(p16[2 * d + 1], p16[2 * d], 0x07050301u);
+  }
+}
+// one 16-channel tile: out[i] = pre-LayerNorm conv output of channel (E/4) kq + 4 ct + i of this lane's token
+template <int E>
+__device__ __forceinline__ void tok_u8_tile(const char* tab, int ct, int lane, int kq, const i32x4& a0, const i32x4& a1, float (&out)[4]) {
+  using T = ItaTokTab<E>;
+  const int c0 = (E / 4) * kq + 4 * ct;
+  // (one weight fragment live at a time, the sums combined in place: the tile runs where the encoder kernel has no register to spare)
+  const i32x4 z = {0, 0, 0, 0};
+  i32x4 s0 = *(const i32x4*)(tab + T::TI + c0 * 4), s1, s2 = *(const i32x4*)(tab + T::TI + (E + c0) * 4), s3;
+  {
+    const i32x4 w0 = *(const i32x4*)(tab + T::TW + ((ct * 3 + 0) * 64 + lane) * 16);
+    s0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, a0, s0, 0, 0, 0);
+    s1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, a1, z, 0, 0, 0);
+  }
+  {
+    const i32x4 w1 = *(const i32x4*)(tab + T::TW + ((ct * 3 + 1) * 64 + lane) * 16);
+    s2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1, a1, s2, 0, 0, 0);
+    s1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1, a0, s1, 0, 0, 0);
+  }
+  {
+    const i32x4 w2 = *(const i32x4*)(tab + T::TW + ((ct * 3 + 2) * 64 + lane) * 16);
+    s3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w2, a1, z, 0, 0, 0);
+    s2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w2, a0, s2, 0, 0, 0);
+  }
+  float lf[4], hf[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { lf[i] = (float)(s0[i] + (s1[i] << 8)); hf[i] = (float)(s2[i] + (s3[i] << 8)); }
+  {
+    const f32x4 sc = *(const f32x4*)(tab + T::TS + c0 * 4), cb = *(const f32x4*)(tab + T::TS + (2 * E + c0) * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lf[i] = fmaf(lf[i], sc[i], cb[i]);
+  }
+  {
+    const f32x4 sc16 = *(const f32x4*)(tab + T::TS + (E + c0) * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = fmaf(hf[i], sc16[i], lf[i]);
+  }
+}
 
 template <int E, bool FFN, bool TOK>
 struct ItaStreamLds {
@@ -89,9 +166,8 @@ struct ItaStreamLds {
   static constexpr int NBIAS = 3 * P + E + (FFN ? F + E : 0);
   static constexpr int LNP = BIAS + NBIAS * 4;       // f32: n1w | n1b | n2w | n2b | tok_lnw | tok_lnb
   static constexpr int NLN = 2 * E + (FFN ? 2 * E : 0) + (TOK ? 2 * E : 0);
-  static constexpr int CW = LNP + NLN * 4;           // f32 [13][4][64]: conv7x7 weights as 16x16x4 A fragments
-  static constexpr int CB = CW + (TOK ? 13 * 4 * 64 * 4 : 0);   // f32 [E]: conv bias
-  static constexpr int TAP = CB + (TOK ? E * 4 : 0);            // int32 [52]: window offset ky * 96 + kx of tap t (0 for t >= 49)
+  static constexpr int CW = LNP + NLN * 4;           // integer conv tables (ItaTokTab<E>): weight byte planes | init sums | scales, bias
+  static constexpr int TAP = CW + (TOK ? ItaTokTab<E>::BYTES : 0);   // int32 [52]: window offset ky * 96 + kx of tap t (0 for t >= 49)
   static constexpr int VB4 = TAP + (TOK ? 52 * 4 : 0);          // int32 [192][4]: bv replicated (V accumulators start per COLUMN)
   static constexpr int IMAGE = VB4 + P * 16;
   static constexpr int GW1 = IMAGE, GW2 = GW1 + F * E;               // W12G: offsets in the global image
@@ -467,9 +543,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       *(i32x4*)(lds + L::IMG + wave * L::IMG_WAVE + g.rr * 96 + 16 * g.pc) =
           (i32x4){(int)o4[0], (int)o4[1], (int)o4[2], (int)o4[3]};
   };
-  // blend: this lane's 13 taps of its token, and the accumulators started at the conv bias
-  float tk_pt[13];
-  f32x4 tk_acc[4];
+  // blend: this lane's 13 taps of its token as exact integers, packed into the two B fragments of the int8 conv
+  i32x4 tk_a0, tk_a1;
+  float tk_out[16];
   auto tok_blend = [&](int ol) {
     const TokGeo g = tok_geo(ol);
     const int kq = ol >> 4;
@@ -477,38 +553,35 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int* tap = (const int*)(lds + L::TAP);
     // The weights of this fixed resize are dyadic, h = H / 8 and w = W / 32 with 0 < H1 < 8, 0 < W1 < 32 for every
     // token, so the blend of a tap is the exact integer  256 * 255 * value = H0 W0 a + H0 W1 b + H1 W0 c + H1 W1 d
-    // on the pixel CODES (each product weight <= 7 * 31 fits a byte); 1 / 65280 is folded into the conv weights
+    // on the pixel CODES (each product weight <= 7 * 31 fits a byte); 1 / 65280 is folded into the conv scales
     // (oracle/ita_oracle.c ita_oracle_tokenizer_u8).  No k / 255 table, no float blend.
     const unsigned H1 = (unsigned)(8.0f * g.h1) & 7u, W1 = (unsigned)(32.0f * g.w1) & 31u, H0 = 8u - H1, W0 = 32u - W1;
     const unsigned w00 = (H0 * W0) & 255u, w01 = (H0 * W1) & 255u, w10 = (H1 * W0) & 255u, w11 = (H1 * W1) & 255u;
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the window is private to this wave
     __builtin_amdgcn_wave_barrier();
+    unsigned pb[13];
 #pragma unroll
     for (int s = 0; s < 13; ++s) {
-      if constexpr (ITA_ABLATE & 512) { tk_pt[s] = (float)(w00 * s); continue; }
+      if constexpr (ITA_ABLATE & 512) { pb[s] = w00 * s; continue; }
       const int off = tap[4 * s + kq];    // ky * 96 + kx of tap 4s + kq (0 for the pad taps 49..51: their weights are 0)
-      const unsigned b256 = (unsigned)win[off] * w00 + (unsigned)win[off + 2] * w01 + (unsigned)win[off + 192] * w10 +
-                            (unsigned)win[off + 194] * w11;
-      tk_pt[s] = (float)b256;
+      pb[s] = (unsigned)win[off] * w00 + (unsigned)win[off + 2] * w01 + (unsigned)win[off + 192] * w10 +
+              (unsigned)win[off + 194] * w11;
     }
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) tk_acc[ct] = *(const f32x4*)(lds + L::CB + (16 * kq + 4 * ct) * 4);
+    tok_u8_fragments(pb, tk_a0, tk_a1);
   };
-  // one k-step (taps 4s .. 4s+3) of the conv: four f32 MFMAs, placed between the VALU-heavy epilogues of the
-  // int8 phases by the caller (the matrix pipe is otherwise idle there)
-  auto tok_step = [&](int s, int ol) {
-    const float* cw = (const float*)(lds + L::CW);
-    if constexpr (ITA_ABLATE & 1024) { tk_acc[s & 3][0] += tk_pt[s]; return; }
+  // one 16-channel tile of the conv: six int8 MFMAs + the float recombination, placed between the phases of the int8
+  // blocks by the caller
+  auto tok_step = [&](int ct, int ol) {
+    if constexpr (ITA_ABLATE & 1024) { tk_out[4 * ct] = __int_as_float(tk_a0[ct]); return; }
+    float o4[4];
+    tok_u8_tile<E>(lds + L::CW, ct, ol, ol >> 4, tk_a0, tk_a1, o4);
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-      tk_acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(cw[(s * 4 + ct) * 64 + ol], tk_pt[s], tk_acc[ct], 0, 0, 0);
+    for (int i = 0; i < 4; ++i) tk_out[4 * ct + i] = o4[i];
   };
   auto tok_finish = [&](int fb, bool store_tap, float (&xr)[EC], int ol) {
     const int qi = ol & 15, kq = ol >> 4, token = wave * 16 + qi;
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xr[4 * ct + i] = tk_acc[ct][i];
+    for (int i = 0; i < 16; ++i) xr[i] = tk_out[i];
     layernorm_q16<E>(xr, lnp + 4 * E, lnp + 5 * E, EC * kq);
     if (a.tok_tap && store_tap) {
       float* o = a.tok_tap + ((size_t)fb * S + token) * E + EC * kq;
@@ -570,7 +643,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       lds_barrier();   // tables in place (the weights are still in flight)
       tok_blend(ol);
 #pragma unroll
-      for (int st = 0; st < 13; ++st) tok_step(st, ol);
+      for (int ct = 0; ct < 4; ++ct) tok_step(ct, ol);
       tok_finish(blockIdx.x, true, xr, ol);
     }
 #pragma unroll
@@ -764,7 +837,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       mm_ks(ob[0], cf[0], oa);
       cf[2] = rq_group(va[2], a.mc, fc);
     }
-    if constexpr (TOK != 0 && !(ITA_ABLATE & 4)) { if (more) tok_blend(ol); }
+    if constexpr (TOK != 0 && !(ITA_ABLATE & 4) && !(ITA_TOK_PLACE == 0 && ITA_TOK_BLEND_END)) { if (more) tok_blend(ol); }
+    if constexpr (TOK != 0 && ITA_TOK_PLACE == 2 && !(ITA_ABLATE & 4)) {
+      if (more) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) tok_step(ct, ol);
+      }
+    }
 
     // ---------------- out_proj + residual + LayerNorm1 (k-step 0 of the first group is already in flight)
     const char* w1p = lds + L::W1;   // fc1 / fc2 weights: LDS image, or (E = 128) the global image behind it
@@ -785,7 +864,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         mm_ks(ob[cur], cf[ks], oa);
         ITA_SCHED_BARRIER();   // keep the step's loads ahead of the next step's MFMAs
       }
-      if constexpr (TOK != 0 && ITA_TOK_MID && !(ITA_ABLATE & 4)) { if (more) { tok_step(0, ol); tok_step(1, ol); } }
+      if constexpr (TOK != 0 && ITA_TOK_MID && !(ITA_ABLATE & 4)) { if (more) tok_step(0, ol); }
       if constexpr (IO8) {   // the int8 codes themselves: 16 channels of this lane's token, one 16-byte store
         *(i32x4*)(a.yq + ((size_t)b * S + token) * E + EC * kq + 16 * eg) = rq_group(oa, a.mo, fo);
         if (eg + 1 < EG) ld_obias<E>(oa, l_bo, 4 * (eg + 1), kq);
@@ -802,7 +881,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int c = 0; c < NK; ++c) xq_cur[c] = xq_nxt[c];
       continue;
     }
-    if constexpr (TOK != 0 && ITA_TOK_MID && !(ITA_ABLATE & 4)) { if (more) { tok_step(2, ol); tok_step(3, ol); } }
     if (FFN || a.fuse_ln) layernorm_q16<E>(x1, lnp, lnp + E, EC * kq);
     if (a.x1_tap) {
       float* o = a.x1_tap + ((size_t)b * S + token) * E + EC * kq;
@@ -831,7 +909,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (g >= 1) ld_frg_ks<E>(wb[(g - 1) & 1], w2p, 0, g - 1, qi, kq);
         mm_group<NK, false>(ffr[g & 1], x1f, fa[g % 3]);
         if (g >= 2) mm_ks(wb[(g - 2) & 1], hf[g - 2], ya);
-        if constexpr (TOK != 0 && ITA_TOK_MID && !(ITA_ABLATE & 4)) { if (more) { tok_step(4 + 2 * g, ol); tok_step(5 + 2 * g, ol); } }
+        if constexpr (TOK != 0 && ITA_TOK_MID && !(ITA_ABLATE & 4)) { if (g < 3 && more) tok_step(1 + g, ol); }
         if (g >= 1) hf[g - 1] = rq_group<true>(fa[(g - 1) % 3], a.m1, false);
         ITA_SCHED_BARRIER();   // keep the step's loads ahead of the next step's MFMAs
       }
@@ -839,7 +917,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       mm_ks(wb[0], hf[2], ya);
       hf[3] = rq_group<true>(fa[3 % 3], a.m1, false);
       mm_ks(wb[1], hf[3], ya);
-      if constexpr (TOK != 0 && ITA_TOK_MID && !(ITA_ABLATE & 4)) { if (more) tok_step(12, ol); }
       ITA_SSTAMP(8);
       {
         float d[16];
@@ -894,10 +971,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     ITA_SSTAMP(11);
     // ---------------- the next frame's tokens
     if constexpr (TOK != 0 && !(ITA_ABLATE & 4)) {
-      if constexpr (!ITA_TOK_MID) {
+      if constexpr (ITA_TOK_PLACE == 0) {
+        if constexpr (ITA_TOK_BLEND_END) { if (more) tok_blend(ol); }   // (the window written after B2 is still in LDS: private to this wave)
         if (more) {
 #pragma unroll
-          for (int st = 0; st < 13; ++st) tok_step(st, ol);
+          for (int ct = 0; ct < 4; ++ct) tok_step(ct, ol);
         }
       }
       if (more) tok_finish(nb, true, xr, ol);
@@ -925,17 +1003,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // the 27 KB of conv fragments), f32 frames (module.main_graph's own input type: four times the window bytes) and callers of
 // ita_tokenizer.  Wave w = token row w of the 8 x 16 grid; one persistent 512-thread workgroup per CU, the next frame's
 // pixels requested a frame ahead.
-//   U8  : the exact integer blend of the pixel codes, conv weights x 1/65280 (oracle: ita_oracle_tokenizer_u8);
+//   U8  : the exact integer blend of the pixel codes and the conv as int8 MFMA on 23-bit fixed-point weights (ItaTokTab,
+//         oracle: ita_oracle_tokenizer_u8) -- the fused tokenizer's functions, bit-identical to it;
 //   !U8 : the oracle's float blend  h0 (w0 a + w1 b) + h1 (w0 c + w1 d)  of pixels already scaled by the caller
-//         (ita_oracle_tokenizer), conv weights as they are.
-// Same results as ita_tokenizer_kernel<E, U8> bit for bit (same operation order), at a fraction of its time.
+//         (ita_oracle_tokenizer), conv weights as they are, v_mfma_f32_16x16x4_f32; same results as
+//         ita_tokenizer_kernel<E, false> bit for bit (same operation order), at a fraction of its time.
 template <int E, bool U8>
 struct ItaTokStreamLds {
   static constexpr int NCT = E / 16;                           // 16-channel output tiles
   static constexpr int LNP = 0;                                // f32: ln_w | ln_b
-  static constexpr int CW = LNP + 2 * E * 4;                   // f32 [13][NCT][64]: conv weights (U8: x 1/65280) as A fragments
-  static constexpr int CB = CW + 13 * NCT * 64 * 4;            // f32 [E]
-  static constexpr int TAP = CB + E * 4;                       // int32 [52]
+  static constexpr int CW = LNP + 2 * E * 4;                   // !U8: f32 [13][NCT][64] conv weights as A fragments; U8: ItaTokTab<E>
+  static constexpr int CB = CW + (U8 ? ItaTokTab<E>::BYTES : 13 * NCT * 64 * 4);   // !U8: f32 [E] conv bias (U8: inside the table)
+  static constexpr int TAP = CB + (U8 ? 0 : E * 4);            // int32 [52]
   static constexpr int IMAGE = TAP + 52 * 4;
   static constexpr int IMG = (IMAGE + 15) & ~15;               // [8 waves][9][96] pixels (u8 or f32), 3 zero columns each side
   static constexpr int IMG_WAVE = 9 * 96 * (U8 ? 1 : 4);
@@ -1015,34 +1094,46 @@ __global__ __launch_bounds__(512) void ita_tok_stream_kernel(const ItaTokStreamA
     if (b + (int)gridDim.x < a.B) fetch(b + gridDim.x);
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the window is private to this wave
     __builtin_amdgcn_wave_barrier();
-    float tk_pt[13];
+    float xr[EC];
+    if constexpr (U8) {
+      const uint8_t* win = (const uint8_t*)wbase + 2 * x0;
+      unsigned pb[13];
 #pragma unroll
-    for (int s = 0; s < 13; ++s) {
-      const int off = tap[4 * s + kq];
-      if constexpr (U8) {
-        const uint8_t* win = (const uint8_t*)wbase + 2 * x0;
-        const unsigned b256 = (unsigned)win[off] * w00 + (unsigned)win[off + 2] * w01 + (unsigned)win[off + 192] * w10 +
-                              (unsigned)win[off + 194] * w11;
-        tk_pt[s] = (float)b256;
-      } else {
+      for (int s = 0; s < 13; ++s) {
+        const int off = tap[4 * s + kq];
+        pb[s] = (unsigned)win[off] * w00 + (unsigned)win[off + 2] * w01 + (unsigned)win[off + 192] * w10 + (unsigned)win[off + 194] * w11;
+      }
+      i32x4 a0, a1;
+      tok_u8_fragments(pb, a0, a1);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        float o4[4];
+        tok_u8_tile<E>(lds + L::CW, ct, lane, kq, a0, a1, o4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xr[4 * ct + i] = o4[i];
+      }
+    } else {
+      float tk_pt[13];
+#pragma unroll
+      for (int s = 0; s < 13; ++s) {
+        const int off = tap[4 * s + kq];
         const float* win = (const float*)wbase + 2 * x0;
         const float va = win[off], vb = win[off + 2], vc = win[off + 192], vd = win[off + 194];
         tk_pt[s] = fh0 * (fw0 * va + w1 * vb) + h1 * (fw0 * vc + w1 * vd);   // ita_oracle_blend_patch's expression
       }
-    }
-    f32x4 acc[NCT];
+      f32x4 acc[NCT];
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) acc[ct] = *(const f32x4*)(lds + L::CB + (EC * kq + 4 * ct) * 4);
+      for (int ct = 0; ct < NCT; ++ct) acc[ct] = *(const f32x4*)(lds + L::CB + (EC * kq + 4 * ct) * 4);
 #pragma unroll
-    for (int s = 0; s < 13; ++s)
+      for (int s = 0; s < 13; ++s)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+          acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(cw[(s * NCT + ct) * 64 + lane], tk_pt[s], acc[ct], 0, 0, 0);
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct)
-        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(cw[(s * NCT + ct) * 64 + lane], tk_pt[s], acc[ct], 0, 0, 0);
-    float xr[EC];
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xr[4 * ct + i] = acc[ct][i];
+        for (int i = 0; i < 4; ++i) xr[4 * ct + i] = acc[ct][i];
+    }
     layernorm_q16<E>(xr, lnp, lnp + E, EC * kq);
     st_tok_quarter<E>(a.tokens + ((size_t)b * S + wave * 16 + qi) * E, kq, xr);   // 64 contiguous bytes per token and store
     __builtin_amdgcn_wave_barrier();      // the window is rewritten for the next frame only after these reads were issued

@@ -166,18 +166,39 @@ int ita_oracle_tokenizer(const float* img, int B, int E, const float* cw, const 
  * pixel by 255.0f and the graph then convolves and resizes in f32; here the pixel codes stay integers as long as they can:
  * the bilinear weights of this fixed 30x45 -> 8x16 resize are dyadic (multiples of 1/8 vertically, 1/32 horizontally), so
  *     B256[tap] = H0*(W0*a + W1*b) + H1*(W0*c + W1*d),   H = 8h, W = 32w,   0 <= B256 <= 255 * 256
- * is an EXACT integer = 256 * 255 * (blended patch value), and the 1 / (255 * 256) goes into the conv weights once:
- *     acc = bias;  acc = fmaf((float)B256[k], w[c][k] * (1.0f / 65280.0f), acc)   k = 0..48.
- * Same linear map as ita_oracle_tokenizer on pixel / 255.0f, with one rounding per weight instead of several per tap --
- * closer to the exact result, and (why it exists) the blend is 4 integer multiply-adds per tap on the GPU instead of a
- * table lookup per pixel plus 9 float operations.  The two entry points agree to ~1e-6, not bit for bit. */
+ * is an EXACT integer = 256 * 255 * (blended patch value).  Since round 3 the convolution is an exact integer too: the
+ * conv weights of a channel become 23-bit fixed point with one power-of-two scale per channel,
+ *     Wq[c][k] = rne(w[c][k] * 2^e_c),  e_c = 22 - exponent(max_k |w[c][k]|)   (|Wq| <= 2^22; all-zero channel: e_c = 0)
+ * and the 49-tap sum runs on BYTES -- B256 = 256 a1 + a0, Wq = 65536 w2 + 256 w1 + w0 with balanced digits w0, w1 in
+ * [-128, 127] -- as four int32 sums (what the GPU's int8 MFMA produces; every grouping is exact):
+ *     S0 = sum a0 w0,  S1 = sum (a0 w1 + a1 w0),  S2 = sum (a0 w2 + a1 w1),  S3 = sum a1 w2
+ *     L = S0 + 256 S1,  H = S2 + 256 S3                      (sum B256 * Wq = 65536 H + L, both below 2^31)
+ *     pre[c] = fmaf((float)H, 65536 s_c, fmaf((float)L, s_c, bias[c])),   s_c = 2^-e_c / 65280.0f
+ * Same linear map as ita_oracle_tokenizer on pixel / 255.0f, closer to the exact result than its 49-step f32 chain (three
+ * f32 roundings instead of forty-nine), and (why it exists) the f32 conv -- v_mfma_f32_16x16x4_f32 runs at the f32 vector
+ * rate and blocks the SIMD's VALU -- becomes 24 int8 MFMAs per wave.  The two entry points agree to ~1e-6, not bit for bit. */
+void ita_oracle_tok_quant_weights(const float* cw, int E, int32_t* wq /*[E][49]*/, float* sc /*[E]*/) {
+  for (int c = 0; c < E; ++c) {
+    float mx = 0.0f;
+    for (int k = 0; k < 49; ++k) mx = fmaxf(mx, fabsf(cw[c * 49 + k]));
+    int e = 0;
+    if (mx > 0.0f) {
+      int ex;
+      (void)frexpf(mx, &ex);      /* mx = m * 2^ex, m in [0.5, 1) */
+      e = 22 - ex;                /* mx * 2^e in [2^21, 2^22) */
+    }
+    for (int k = 0; k < 49; ++k) wq[c * 49 + k] = (int32_t)rintf(ldexpf(cw[c * 49 + k], e));
+    sc[c] = ldexpf(1.0f, -e) / 65280.0f;
+  }
+}
+
 int ita_oracle_tokenizer_u8(const uint8_t* img, int B, int E, const float* cw, const float* cb, const float* lnw,
                             const float* lnb, float* tokens) {
-  float pb[49];
+  int32_t pb[49];
   float* pre = (float*)malloc(sizeof(float) * (size_t)E);
-  float* ws = (float*)malloc(sizeof(float) * (size_t)E * 49);
-  const float inv = 1.0f / 65280.0f;
-  for (int i = 0; i < E * 49; ++i) ws[i] = cw[i] * inv;
+  int32_t* wq = (int32_t*)malloc(sizeof(int32_t) * (size_t)E * 49);
+  float* sc = (float*)malloc(sizeof(float) * (size_t)E);
+  ita_oracle_tok_quant_weights(cw, E, wq, sc);
   int rc = 0;
   for (int b = 0; b < B && !rc; ++b)
     for (int oy = 0; oy < TOK_H && !rc; ++oy)
@@ -196,16 +217,23 @@ int ita_oracle_tokenizer_u8(const uint8_t* img, int B, int E, const float* cw, c
 #define PX_(y, x) (((y) < 0 || (y) >= IMG_H || (x) < 0 || (x) >= IMG_W) ? 0 : (int)im[(y) * IMG_W + (x)])
             const int a = PX_(iy, ix), bb = PX_(iy, ix + 2 * xp), c = PX_(iy + 2 * yp, ix), d = PX_(iy + 2 * yp, ix + 2 * xp);
 #undef PX_
-            pb[ky * 7 + kx] = (float)(H0 * (W0 * a + W1 * bb) + H1 * (W0 * c + W1 * d));
+            pb[ky * 7 + kx] = H0 * (W0 * a + W1 * bb) + H1 * (W0 * c + W1 * d);
           }
         for (int c = 0; c < E; ++c) {
-          float acc = cb[c];
-          for (int k = 0; k < 49; ++k) acc = fmaf(pb[k], ws[c * 49 + k], acc);
-          pre[c] = acc;
+          int32_t S0 = 0, S1 = 0, S2 = 0, S3 = 0;
+          for (int k = 0; k < 49; ++k) {
+            const int32_t a0 = pb[k] & 255, a1 = pb[k] >> 8;
+            const int32_t W = wq[c * 49 + k];
+            const int32_t w0 = ((W + 128) & 255) - 128, W1r = (W - w0) >> 8;
+            const int32_t w1 = ((W1r + 128) & 255) - 128, w2 = (W1r - w1) >> 8;
+            S0 += a0 * w0; S1 += a0 * w1 + a1 * w0; S2 += a0 * w2 + a1 * w1; S3 += a1 * w2;
+          }
+          const int32_t L = S0 + 256 * S1, Hh = S2 + 256 * S3;
+          pre[c] = fmaf((float)Hh, 65536.0f * sc[c], fmaf((float)L, sc[c], cb[c]));
         }
         layernorm_row(pre, E, lnw, lnb, tokens + ((size_t)b * 128 + oy * TOK_W + ox) * E);
       }
-  free(pre); free(ws);
+  free(pre); free(wq); free(sc);
   return rc;
 }
 

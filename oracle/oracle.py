@@ -205,6 +205,29 @@ def head_from_dec(dec, desvel, quat, fp, h_in=None, c_in=None):
     return linear_f32(x, fp["nn_fc2.weight"], fp["nn_fc2.bias"]), h, c
 
 
+def forward_from_tokens(tokens, block_tensors, fp, num_layers, desvel, quat, h_in=None, c_in=None):
+    """the graph BEHIND the tokenizer, composed from the block entry points above (QAT/model.py:100-130): encoder layers,
+    fusion tail (when fp holds `down_sample.*`) or the flattened tokens, decoder, LSTM head.  block_tensors: blob-name keyed
+    int8 tensors of every layer (params.attention_tensors / ffn_tensors), fp: float parameters.  Lets a test start from
+    the REFERENCE's token tensor, so that what follows is free of the tokenizer's float noise.
+    Returns (vel, h, c, {"x1": last layer's LayerNorm1 output, "x2", "dec", "x_q0": layer 0's input codes})."""
+    x = _c(tokens, np.float32)
+    B = x.shape[0]
+    x1, xq0 = None, None
+    for l in range(num_layers):
+        a, tp = mha(x, block_tensors, l, taps=True)
+        if l == 0:
+            xq0 = tp["x_q"]
+        x1 = add_ln(x, a, fp[f"norms1.{l}.weight"], fp[f"norms1.{l}.bias"])
+        x = add_ln(x1, ffn(x1, block_tensors, l), fp[f"norms2.{l}.weight"], fp[f"norms2.{l}.bias"])
+    if "down_sample.weight" in fp:
+        dec = linear_f32(tail(x, fp["down_sample.weight"], fp["down_sample.bias"]), fp["decoder.weight"], fp["decoder.bias"])
+    else:
+        dec = linear_f32(x.reshape(B, -1), fp["decoder.weight"], fp["decoder.bias"])
+    vel, h, c = head_from_dec(dec, desvel, quat, fp, h_in, c_in)
+    return vel, h, c, {"x1": x1, "x2": x, "dec": dec, "x_q0": xq0}
+
+
 def forward(blob: bytes, image, desvel, quat, h_in=None, c_in=None, taps=False):
     """module.main_graph semantics with leading batch (QAT/model.py:93-132)."""
     image = np.ascontiguousarray(image)

@@ -179,6 +179,59 @@ def test_lstm_head_from_fixture_decoder(oracle, path):
             np.testing.assert_allclose(got, d[key], atol=1e-6, rtol=0, err_msg=key)
 
 
+def _all_block_tensors(d, nl):
+    t = {}
+    for l in range(nl):
+        t.update(params.attention_tensors(d, f"attn{l}.", l))
+        t.update(params.ffn_tensors(d, f"ffn{l}.", l))
+    return t
+
+
+FIX_GRAPHS = FIX_VIT + golden_files("vit2l_*.npz") + golden_files("vit1l_*.npz")
+
+
+@pytest.mark.parametrize("path", FIX_GRAPHS, ids=_ids(FIX_GRAPHS))
+def test_forward_from_reference_tokens(oracle, path):
+    """Everything BEHIND the tokenizer, started from the reference's own token tensor: encoder layer(s) with their int8
+    blocks, fusion tail / flattened tokens, decoder, LSTM head -- against the reference's outputs of the same forward.
+    No float stage of ours sits in front of the first quantiser here, so no input code can flip: what is left is the
+    documented near-tie exception of matmul1 (<= 3 logits per fixture).  Bounds: velocity 1e-5, h and c 5e-4, x2 2e-6
+    except in rows a near-tie logit touches.  The from-the-image tests below add the tokenizer (<= 2e-6 on the tokens)
+    and have to allow for input codes that sit on a rounding tie; this test is the tight one."""
+    d = params.load_fixture(path)
+    E = int(d["meta.E"]) if "meta.E" in d else 64
+    nl = int(d["meta.num_layers"]) if "meta.num_layers" in d else 1
+    fp = synth.float_params(int(d["meta.seed"]), E=E, num_layers=nl, tail=(E == 64))
+    t = _all_block_tensors(d, nl)
+    vel, h, c, o = oracle.forward_from_tokens(d["s0.tok.out"], t, fp, nl, d["in0.desvel"], d["in0.quat"])
+    np.testing.assert_array_equal(o["x_q0"], d["s0.attn0.x_q"])                   # the first quantiser: bit-exact
+    x2_ref = d[f"s0.x2_{nl - 1}"] if f"s0.x2_{nl - 1}" in d else d["s0.x2"]
+    off = np.abs(o["x2"] - x2_ref) > 2e-6
+    assert off.any(axis=-1).sum() <= (3 if nl == 1 else 2 * 128)   # one layer: the touched rows; two: layer 1 mixes them into every row of a frame
+    np.testing.assert_allclose(o["x2"], x2_ref, atol=1e-2, rtol=0)
+    np.testing.assert_allclose(vel, d["s0.vel"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(h, d["s0.h"], atol=5e-4, rtol=0)
+    np.testing.assert_allclose(c, d["s0.c"], atol=5e-4, rtol=0)
+    # against oracle.forward's own composition from the same tokens: identical
+    blob = params.blob_from_record(d, fp, E=E, num_layers=nl)
+    v2, h2, c2, tp = oracle.forward(blob, d["in0.img_u8"], d["in0.desvel"], d["in0.quat"], taps=True)
+    v3, h3, c3, o3 = oracle.forward_from_tokens(tp["tokens"], t, fp, nl, d["in0.desvel"], d["in0.quat"])
+    np.testing.assert_array_equal(v3, v2); np.testing.assert_array_equal(h3, h2); np.testing.assert_array_equal(o3["x2"], tp["x2"])
+
+
+def _input_code_flips(oracle, d, tokens, t):
+    """layer-0 input codes that differ from the reference's, each checked to be a rounding tie within float noise"""
+    xq = oracle.quantize(tokens, t["attn0.scal"][0])
+    ref = d["s0.attn0.x_q"]
+    idx = np.argwhere(xq != ref)
+    for i in idx:
+        i = tuple(i)
+        assert abs(int(xq[i]) - int(ref[i])) == 1
+        scaled = float(d["s0.tok.out"][i]) * float(t["attn0.scal"][0])
+        assert abs(abs(scaled - np.floor(scaled)) - 0.5) < 1e-3, scaled          # the reference's own value sits on the tie
+    return len(idx)
+
+
 @pytest.mark.parametrize("path", FIX_VIT, ids=_ids(FIX_VIT))
 def test_full_forward_two_steps(oracle, path):
     """module.main_graph twice, carrying (h, c) like the reference host.  The int8 blocks sit
@@ -188,17 +241,23 @@ def test_full_forward_two_steps(oracle, path):
     fp = synth.float_params(int(d["meta.seed"]), E=64)
     blob = params.blob_from_record(d, fp, E=64)
     vel0, h0, c0, tp = oracle.forward(blob, d["in0.img_u8"], d["in0.desvel"], d["in0.quat"], taps=True)
-    np.testing.assert_allclose(tp["tokens"], d["s0.tok.out"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(tp["tokens"], d["s0.tok.out"], atol=4e-6, rtol=0)
     np.testing.assert_allclose(tp["x1"], d["s0.x1"], atol=5e-2, rtol=0)
-    assert np.mean(np.abs(tp["x1"] - d["s0.x1"]) > 1e-4) < 2e-3      # isolated int8 flips only
+    # isolated int8 flips only: an input code that sits on a rounding tie may flip behind the 1e-6 float difference of the
+    # tokenizer (each such code is checked to BE a tie in the reference's own tokens), and then its whole token row of x1
+    # moves -- at most 2 of the 256 token rows.  test_forward_from_reference_tokens is the same forward without that noise.
+    assert _input_code_flips(oracle, d, tp["tokens"], params.attention_tensors(d, "attn0.", 0)) <= 2
+    assert int((np.abs(tp["x1"] - d["s0.x1"]) > 1e-4).any(axis=-1).sum()) <= 2
     np.testing.assert_allclose(tp["dec"], d["s0.dec"], atol=2e-3, rtol=0)
     np.testing.assert_allclose(vel0, d["s0.vel"], atol=5e-4, rtol=0)
     np.testing.assert_allclose(h0, d["s0.h"], atol=5e-4, rtol=0)
-    np.testing.assert_allclose(c0, d["s0.c"], atol=5e-4, rtol=0)
+    # (c is the unbounded cell state: one flipped token row moves it by up to 8.5e-4 on the seed-2 fixture -- same 1e-3 bound
+    #  as the E = 128 family below; h = o * tanh(c) and the velocity stay inside 5e-4)
+    np.testing.assert_allclose(c0, d["s0.c"], atol=1e-3, rtol=0)
     vel1, h1, c1 = oracle.forward(blob, d["in1.img_u8"], d["in1.desvel"], d["in1.quat"], d["s0.h"], d["s0.c"])
     np.testing.assert_allclose(vel1, d["s1.vel"], atol=5e-4, rtol=0)
     np.testing.assert_allclose(h1, d["s1.h"], atol=5e-4, rtol=0)
-    np.testing.assert_allclose(c1, d["s1.c"], atol=5e-4, rtol=0)
+    np.testing.assert_allclose(c1, d["s1.c"], atol=1e-3, rtol=0)
     # float-image entry point (float(pixel) / 255.0f and the float blend) against the u8 wire entry point (integer
     # blend of the pixel codes, 1/65280 in the conv weights): the same linear map, rounded differently -- the tokens
     # agree to 4e-6, the velocity to what the int8 blocks allow behind such a difference
@@ -231,16 +290,19 @@ def test_two_layer_no_tail_graph(oracle, path):
     np.testing.assert_array_equal(tp["x_q"], d["s0.attn0.x_q"])
     assert (tp["out_q"] != d["s0.attn0.out_q"]).mean() < 2e-3                    # near-tie logits only (see test_mha)
     vel0, h0, c0, tpf = oracle.forward(blob, d["in0.img_u8"], d["in0.desvel"], d["in0.quat"], taps=True)
-    np.testing.assert_allclose(tpf["tokens"], d["s0.tok.out"], atol=2e-5, rtol=0)
-    assert np.mean(np.abs(tpf["x2"] - d[f"s0.x2_{nl - 1}"]) > 1e-4) < 5e-3
-    np.testing.assert_allclose(tpf["dec"], d["s0.dec"], atol=5e-3, rtol=0)
-    # (the cell state is not squashed: the decoder's K = 16384 sum carries a flipped int8 code into it at up to 6e-4 on the
-    #  seed-1 fixture; velocity and h stay inside 5e-4)
+    np.testing.assert_allclose(tpf["tokens"], d["s0.tok.out"], atol=4e-6, rtol=0)
+    assert _input_code_flips(oracle, d, tpf["tokens"], t0) <= 2
+    # From the image the 1e-6 float difference of the tokens can flip a code at ANY of the graph's quantisers (four per layer),
+    # and in the two-layer graph layer 1's attention then mixes the moved row into every row of its frame; the K = 16384
+    # decoder sum carries that into the unsquashed cell state.  Observed over the fixtures and both image entry points: up to
+    # 3.5e-3 on h, 5.5e-3 on c, 3e-5 on the velocity.  The same forward from the reference's own tokens
+    # (test_forward_from_reference_tokens) stays inside 5e-4 / 1e-5: the difference is flips, not arithmetic.
+    np.testing.assert_allclose(tpf["dec"], d["s0.dec"], atol=2e-2, rtol=0)
     for got, key in ((vel0, "s0.vel"), (h0, "s0.h"), (c0, "s0.c")):
-        np.testing.assert_allclose(got, d[key], atol=1e-3 if key.endswith(".c") else 5e-4, rtol=0, err_msg=key)
+        np.testing.assert_allclose(got, d[key], atol=5e-4 if key.endswith("vel") else 1e-2, rtol=0, err_msg=key)
     vel1, h1, c1 = oracle.forward(blob, d["in1.img_u8"], d["in1.desvel"], d["in1.quat"], d["s0.h"], d["s0.c"])
     for got, key in ((vel1, "s1.vel"), (h1, "s1.h"), (c1, "s1.c")):
-        np.testing.assert_allclose(got, d[key], atol=1e-3 if key.endswith(".c") else 5e-4, rtol=0, err_msg=key)
+        np.testing.assert_allclose(got, d[key], atol=5e-4 if key.endswith("vel") else 1e-2, rtol=0, err_msg=key)
     # the float head from the reference's decoder output: 1e-6
     fpr = dict(fp)
     vel, h, c = oracle.head_from_dec(d["s0.dec"], d["in0.desvel"], d["in0.quat"], fpr)
