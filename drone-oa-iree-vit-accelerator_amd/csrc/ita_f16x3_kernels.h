@@ -572,6 +572,7 @@ struct ItaTailBigArgs {
   float inv_wscale;
   float* out;                     // (B, CO, 2TH, 2TW)
   int B, E, TH, TW, CO, nchunk;
+  int accumulate;                 // 1: out += this kernel's part (no bias): the upsample channels came from ita_tail_up_kernel
 };
 template <int NT, int WAVES, int TPS>
 struct ItaTailBigLds {
@@ -734,11 +735,286 @@ __global__ __launch_bounds__(64 * WAVES) void ita_tail_big_kernel(const ItaTailB
     for (int nt = 0; nt < NT; ++nt) {
       const int co = nt * 16 + co_l;
       if (co < a.CO) {
-        const float bv = a.bias[co];
-        f32x4 o;
+        const float bv = a.accumulate ? 0.0f : a.bias[co];
+        float* op = a.out + (((size_t)b * a.CO + co) * OH + y) * OW + x;
+        f32x4 o = a.accumulate ? *(const f32x4*)op : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = acc[mt][nt][i] * a.inv_wscale + bv;
-        *(f32x4*)(a.out + (((size_t)b * a.CO + co) * OH + y) * OW + x) = o;
+        for (int i = 0; i < 4; ++i) o[i] = o[i] + (acc[mt][nt][i] * a.inv_wscale + bv);
+        *(f32x4*)op = o;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ fusion tail on large token grids: the upsample branch by linearity
+// The 4E/5 upsampled channels of the concatenated map are bilinear interpolations of the TOKENS, and conv3x3 is linear, so for
+// every tap t the channel contraction commutes with the interpolation:
+//     sum_c W[co][c][t] * U[q][c]  =  sum_{s in 4 neighbours of q} I[q][s] * Y_t[s][co],     Y_t[s][co] = sum_c W[co][c][t] * x[s][c]
+// -- Y_t is a GEMM over the LOW-RESOLUTION tokens (a quarter of the pixels: 4x fewer MACs than the implicit GEMM on the
+// upsampled map, and no upsampled map, halo build or hi/lo split of 160 x 32768 values per frame), the interpolation an
+// exact f32 blend of four Y rows per tap.  Zero padding of the conv = taps whose position q falls outside the map are skipped.
+//   workgroup (512 threads) = one 16 x 32 output tile, all output channels; its source region is at most 10 x 18 tokens (host-checked)
+//   = 12 M tiles of 16 tokens: wave w owns tiles w and w + 8 (w < 4) -- a SIMD hosts waves w and w + 4, so the MFMA load per
+//   SIMD is equal -- with the tokens' f16 hi / lo fragments resident in registers for all nine taps;
+//   per tap: Y_t = W_t . x^T on v_mfma_f32_16x16x32_f16 (three split-precision products, weights as the A operand so that a
+//   lane holds four consecutive output channels of one token: one 16-byte LDS store) -> Y slab [192 tokens][52] f32 in LDS;
+//   blend: thread = output pixel, 48 accumulators, four Y rows per tap (12 x ds_read_b128 each) with v_pk_fma_f32;
+//   one barrier per tap: GEMM(t) and blend(t - 1) of a wave run back to back, two Y slabs, two weight buffers (LDS-DMA).
+// The E/4 pixel-shuffle channels are no interpolation: phase 2 of the same workgroup runs them as the implicit GEMM of
+// ita_tail_big_kernel's chunk 0 (gathered halo in LDS), and the two parts are added in LDS and stored once, 16 bytes per lane.
+struct ItaTailUpArgs {
+  const float* x;                  // (B, TH*TW, 128)
+  const _Float16 *w_hi, *w_lo;     // [9 taps][4 k-steps][3 N tiles][64 lanes][8]: A fragments (row = output channel), pre-scaled
+  const _Float16 *s_hi, *s_lo;     // pixel-shuffle channels (conv input channels 0..31): [9 taps][48][32], same scale, zero rows beyond CO
+  const float* bias;               // [48]
+  float inv_wscale;
+  float* out;                      // (B, CO, 2TH, 2TW)
+  int B, TH, TW, CO;
+};
+struct ItaTailUpLds {
+  static constexpr int RH = 10, RW = 18, NTOK = 192;
+  static constexpr int YLD = 52;                             // floats per token row (48 + 4: conflict-free 16-byte stores and loads)
+  static constexpr int YB = NTOK * YLD * 4;                  // bytes per Y slab
+  static constexpr int Y = 0;
+  static constexpr int WPL = 4 * 3 * 1024;                   // bytes per weight plane and tap
+  static constexpr int W = 2 * YB;                           // two buffers x (hi | lo)
+  static constexpr int TOTAL1 = W + 2 * 2 * WPL;             // phase 1: two Y slabs + two weight buffers
+  static constexpr int TOTAL2 = 2 * (18 * 34 * 64) + 2 * (9 * 48 * 64);   // phase 2: shuffle halo hi | lo, its weights hi | lo (>= U [48][516] f32)
+  static constexpr int TOTAL = TOTAL1 > TOTAL2 ? TOTAL1 : TOTAL2;
+  static_assert(48 * 516 * 4 <= TOTAL2 && TOTAL <= 160 * 1024, "LDS budget");
+};
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void ita_tail_up_kernel(const ItaTailUpArgs a) {
+  using L = ItaTailUpLds;
+  constexpr int E = 128;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int OH = 2 * a.TH, OW = 2 * a.TW;
+  const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 16, b = blockIdx.z;
+  const float* xt = a.x + (size_t)b * a.TH * a.TW * E;
+  const float sy = (float)(a.TH - 1) / (float)(OH - 1), sx = (float)(a.TW - 1) / (float)(OW - 1);
+  // source row / column of a clamped output coordinate: the oracle's upsample_src_ac (bilinear x2, align_corners=True)
+  auto src = [](int q, float s, int n, int& i0, int& ip, float& l1) {
+    const float f = s * (float)q;
+    int i = (int)f;
+    if (i > n - 1) i = n - 1;
+    i0 = i; ip = i < n - 1 ? 1 : 0; l1 = f - (float)i;
+  };
+  int ry0, rx0, dummy_i; float dummy_f;
+  src(max(ty0 - 1, 0), sy, a.TH, ry0, dummy_i, dummy_f);
+  src(max(tx0 - 1, 0), sx, a.TW, rx0, dummy_i, dummy_f);
+
+  // ---- weights of taps 0 and 1 on their way into LDS (LDS-DMA: 24 pieces of 1 KB per tap, three per wave)
+  auto stage_w = [&](int tap) {
+    const int buf = tap & 1;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int piece = wave + 8 * q;                      // 0..23: hi plane pieces 0..11, lo plane 12..23
+      const _Float16* g = (piece < 12 ? a.w_hi : a.w_lo) + (size_t)tap * (L::WPL / 2) + (size_t)(piece % 12) * 512 + lane * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(lds + L::W + buf * 2 * L::WPL + piece * 1024), 16, 0, 0);
+    }
+  };
+  stage_w(0);
+
+  // ---- this wave's token tiles as B fragments (column = token, k = 8 (lane >> 4) .. + 7 of each 32-channel k-step), f16 hi / lo
+  const int nmt = wave < 4 ? 2 : 1;
+  f16x8 xh[2][4], xl[2][4];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int slot = min(16 * (wave + 8 * m) + (lane & 15), L::RH * L::RW - 1);   // (slots 180..191 and the light waves' second tile: unused copies)
+    const int r = slot / L::RW, c = slot - L::RW * r;
+    const float* tp = xt + ((size_t)min(ry0 + r, a.TH - 1) * a.TW + min(rx0 + c, a.TW - 1)) * E + 8 * (lane >> 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 v0 = *(const f32x4*)(tp + 32 * j), v1 = *(const f32x4*)(tp + 32 * j + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        _Float16 h, l;
+        split_f16(v0[e], h, l); xh[m][j][e] = h; xl[m][j][e] = l;
+        split_f16(v1[e], h, l); xh[m][j][4 + e] = h; xl[m][j][4 + e] = l;
+      }
+    }
+  }
+
+  // ---- geometry of this thread's output pixel: source rows for dy = -1, 0, 1 and source columns for dx = -1, 0, 1
+  const int py = ty0 + (tid >> 5), px = tx0 + (tid & 31);
+  int rowo[3], colo[3], ypo[3], xpo[3];      // Y-slab float offset of the row / column, offset of the second row / column
+  float h1v[3], w1v[3], vy[3], vx[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    int i0, ip; float l1;
+    const int qy = py + d - 1, qx = px + d - 1;
+    src(min(max(qy, 0), OH - 1), sy, a.TH, i0, ip, l1);
+    rowo[d] = (i0 - ry0) * L::RW * L::YLD; ypo[d] = ip * L::RW * L::YLD; h1v[d] = l1; vy[d] = (qy >= 0 && qy < OH) ? 1.0f : 0.0f;
+    src(min(max(qx, 0), OW - 1), sx, a.TW, i0, ip, l1);
+    colo[d] = (i0 - rx0) * L::YLD; xpo[d] = ip * L::YLD; w1v[d] = l1; vx[d] = (qx >= 0 && qx < OW) ? 1.0f : 0.0f;
+  }
+  f32x4 acc[12];
+#pragma unroll
+  for (int g = 0; g < 12; ++g) acc[g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+
+  auto gemm = [&](int t) {
+    const char* wb = lds + L::W + (t & 1) * 2 * L::WPL;
+    float* ys = (float*)(lds + L::Y + (t & 1) * L::YB);
+    f32x4 c[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt) c[m][nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f16x8 wh[3], wl[3];
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt) {
+        wh[nt] = *(const f16x8*)(wb + ((j * 3 + nt) * 64 + lane) * 16);
+        wl[nt] = *(const f16x8*)(wb + L::WPL + ((j * 3 + nt) * 64 + lane) * 16);
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        if (m < nmt) {
+#pragma unroll
+          for (int nt = 0; nt < 3; ++nt) {
+            c[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], xl[m][j], c[m][nt], 0, 0, 0);
+            c[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], xh[m][j], c[m][nt], 0, 0, 0);
+            c[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], xh[m][j], c[m][nt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // C layout: lane = (token column lane & 15, output channels 4 (lane >> 4) .. + 3 of N tile nt)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+      if (m < nmt) {
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt)
+          *(f32x4*)(ys + (16 * (wave + 8 * m) + (lane & 15)) * L::YLD + 16 * nt + 4 * (lane >> 4)) = c[m][nt];
+      }
+  };
+  auto blend = [&](int t) {
+    const int dy = t / 3, dx = t - 3 * dy;
+    const float* ys = (const float*)(lds + L::Y + (t & 1) * L::YB);
+    const float ok = vy[dy] * vx[dx];                              // 0: the tap's position lies in the conv's zero padding
+    const float h1 = h1v[dy], h0 = 1.0f - h1, w1 = w1v[dx], w0 = 1.0f - w1;
+    const float k00 = ok * (h0 * w0), k01 = ok * (h0 * w1), k10 = ok * (h1 * w0), k11 = ok * (h1 * w1);
+    const f32x4 q00 = {k00, k00, k00, k00}, q01 = {k01, k01, k01, k01}, q10 = {k10, k10, k10, k10}, q11 = {k11, k11, k11, k11};
+    const float* p00 = ys + rowo[dy] + colo[dx];
+    const float* p01 = p00 + xpo[dx];
+    const float* p10 = p00 + ypo[dy];
+    const float* p11 = p10 + xpo[dx];
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {
+      const f32x4 v00 = *(const f32x4*)(p00 + 4 * g), v01 = *(const f32x4*)(p01 + 4 * g);
+      const f32x4 v10 = *(const f32x4*)(p10 + 4 * g), v11 = *(const f32x4*)(p11 + 4 * g);
+      // (explicit fma: the library is built with -ffp-contract=off)
+      acc[g] = __builtin_elementwise_fma(q00, v00, acc[g]);
+      acc[g] = __builtin_elementwise_fma(q01, v01, acc[g]);
+      acc[g] = __builtin_elementwise_fma(q10, v10, acc[g]);
+      acc[g] = __builtin_elementwise_fma(q11, v11, acc[g]);
+    }
+  };
+
+#pragma unroll 1
+  for (int t = 0; t < 9; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of W[t] have landed
+    __syncthreads();                                   // W[t] complete; GEMM(t-1) done by every wave: Y[(t-1)&1] complete, W[(t+1)&1] free; blend(t-2) done: Y[t&1] free
+    if (t + 1 < 9) stage_w(t + 1);
+#ifndef ITA_UP_ABLATE
+#define ITA_UP_ABLATE 0
+#endif
+    if (!(ITA_UP_ABLATE & 1)) gemm(t);
+    if (!(ITA_UP_ABLATE & 2)) { if (t > 0) blend(t - 1); }
+  }
+  __syncthreads();
+  if (!(ITA_UP_ABLATE & 2)) blend(8);
+
+  // ================= phase 2: the E/4 pixel-shuffle channels -- a plain gather of token channels, no interpolation -- as an
+  // implicit GEMM on the 18 x 34 halo of this tile (ita_tail_big_kernel's chunk 0, same fragments and weights), then both
+  // parts meet in LDS and leave as 16-byte stores.  Phase 1's LDS is dead: [halo hi | halo lo | weights hi | weights lo].
+  __syncthreads();
+  {
+    constexpr int HP = 18 * 34, A_PLANE = HP * 64, W_PLANE = 9 * 48 * 64;
+    constexpr int AH = 0, AL = A_PLANE, WH = 2 * A_PLANE, WL = WH + W_PLANE;
+    static_assert(WL + W_PLANE <= L::TOTAL2, "phase-2 LDS");
+    for (int wc = wave; wc < W_PLANE / 1024; wc += 8) {     // 27 pieces per plane
+      const int piece = wc * 64 + lane;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.s_hi + piece * 8),
+                                       (__attribute__((address_space(3))) void*)(lds + WH + wc * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.s_lo + piece * 8),
+                                       (__attribute__((address_space(3))) void*)(lds + WL + wc * 1024), 16, 0, 0);
+    }
+    // halo of the shuffled map: PixelShuffle(2): out[c][2h+i][2w+j] = in[4c+2i+j][h][w]; item = (pixel, 4 channels)
+    for (int i0 = tid; i0 < HP * 8; i0 += 512) {
+      const int p = i0 >> 3, cq = i0 & 7;
+      const int hy = p / 34, hx = p - 34 * hy;
+      const int y = ty0 + hy - 1, x = tx0 + hx - 1;
+      const bool ok = y >= 0 && y < OH && x >= 0 && x < OW;
+      const int yc = min(max(y, 0), OH - 1), xc = min(max(x, 0), OW - 1);
+      const float* t = xt + ((size_t)(yc >> 1) * a.TW + (xc >> 1)) * E + 2 * (yc & 1) + (xc & 1) + 16 * cq;
+      f16x4 vh, vl;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v = ok ? t[4 * j] : 0.0f;
+        _Float16 hq, lq;
+        split_f16(v, hq, lq);
+        vh[j] = hq; vl[j] = lq;
+      }
+      *(f16x4*)(lds + AH + p * 64 + cq * 8) = vh;
+      *(f16x4*)(lds + AL + p * 64 + cq * 8) = vl;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x4 acc2[4][3];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt) acc2[mt][nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    const int pxl = lane & 15, kg = lane >> 4;
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      f16x8 bh[3], bl[3];
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt) {
+        const int off = ((tap * 48 + nt * 16 + pxl) * 64) + kg * 16;
+        bh[nt] = *(const f16x8*)(lds + WH + off);
+        bl[nt] = *(const f16x8*)(lds + WL + off);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int hp = (2 * wave + (mt >> 1) + ky) * 34 + (mt & 1) * 16 + pxl + kx;
+        const f16x8 ah = *(const f16x8*)(lds + AH + hp * 64 + kg * 16);
+        const f16x8 al = *(const f16x8*)(lds + AL + hp * 64 + kg * 16);
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+          acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[nt], acc2[mt][nt], 0, 0, 0);
+          acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[nt], acc2[mt][nt], 0, 0, 0);
+          acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[nt], acc2[mt][nt], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();       // halo and weights consumed: the interpolated part moves into LDS as U[co][pixel] (row stride 516)
+    float* U = (float*)lds;
+#pragma unroll
+    for (int g = 0; g < 12; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) U[(4 * g + i) * 516 + tid] = acc[g][i] * a.inv_wscale + a.bias[4 * g + i];
+    __syncthreads();
+    // C layout of phase 2: lane = (output channel 16 nt + lane & 15, pixels 4 (lane >> 4) .. + 3 of M tile mt): 16-byte stores
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int row = 2 * wave + (mt >> 1), col = (mt & 1) * 16 + 4 * kg;
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt) {
+        const int co = nt * 16 + pxl;
+        if (co < a.CO) {
+          const f32x4 u = *(const f32x4*)(U + co * 516 + row * 32 + col);
+          f32x4 o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] = u[i] + acc2[mt][nt][i] * a.inv_wscale;
+          *(f32x4*)(a.out + (((size_t)b * a.CO + co) * OH + ty0 + row) * OW + tx0 + col) = o;
+        }
       }
     }
   }

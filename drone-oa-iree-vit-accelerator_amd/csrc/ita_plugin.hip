@@ -107,6 +107,8 @@ struct ita_context {
   int pipe_cap = 0;
   // fusion tail on large token grids (ita_fusion_tail_load / _large, BASELINE config 5)
   _Float16 *tl_hi = nullptr, *tl_lo = nullptr;   // [chunks][9][nt*16][32]
+  _Float16 *tu_hi = nullptr, *tu_lo = nullptr;   // upsample branch by linearity (ita_tail_up_kernel): [9][4][3][64][8], E = 128 only
+  _Float16 *ts_hi = nullptr, *ts_lo = nullptr;   // its phase 2, the pixel-shuffle channels: [9][48][32] (48 rows whatever out_ch is)
   float* tl_bias = nullptr;
   float tl_inv_scale = 1.0f;
   int tl_E = 0, tl_CO = 0, tl_nt = 0, tl_nchunk = 0;
@@ -841,6 +843,7 @@ int ita_create(ita_handle* out, int device_ordinal) {
   if ((rc = set_lds(ita_tokenizer_kernel<128, true>, ita_tok_lds_bytes<128>()))) { delete c; return rc; }
   if ((rc = set_lds(ita_tokenizer_kernel<128, false>, ita_tok_lds_bytes<128>()))) { delete c; return rc; }
   if ((rc = set_lds(ita_tail_kernel<64>, ita_tail_lds_bytes<64>()))) { delete c; return rc; }
+  if ((rc = set_lds(ita_tail_up_kernel, ItaTailUpLds::TOTAL))) { delete c; return rc; }
   if ((rc = set_lds(ita_stream_kernel<64, true, 1, false, false, true>, ItaStreamLds<64, true, true>::TOTAL))) { delete c; return rc; }
   if ((rc = set_lds(ita_stream_kernel<64, true, 0, false, false, true>, ItaStreamLds<64, true, false>::TOTAL))) { delete c; return rc; }
   if ((rc = set_lds(ita_stream_kernel<64, false, 0, false, false, true>, ItaStreamLds<64, false, false>::TOTAL))) { delete c; return rc; }
@@ -1202,6 +1205,11 @@ static void free_tail_large(ita_context* c) {
   if (c->tl_hi) (void)hipFree(c->tl_hi);
   if (c->tl_lo) (void)hipFree(c->tl_lo);
   if (c->tl_bias) (void)hipFree(c->tl_bias);
+  if (c->tu_hi) (void)hipFree(c->tu_hi);
+  if (c->tu_lo) (void)hipFree(c->tu_lo);
+  if (c->ts_hi) (void)hipFree(c->ts_hi);
+  if (c->ts_lo) (void)hipFree(c->ts_lo);
+  c->tu_hi = c->tu_lo = c->ts_hi = c->ts_lo = nullptr;
   c->tl_hi = c->tl_lo = nullptr;
   c->tl_bias = nullptr;
   c->tl_E = c->tl_CO = c->tl_nt = c->tl_nchunk = 0;
@@ -1229,8 +1237,42 @@ int ita_fusion_tail_load(ita_handle h, const float* conv_w, const float* conv_b,
         hi[d] = float_to_half(v);
         lo[d] = float_to_half(v - half_to_float(hi[d]));
       }
-  std::vector<float> bias(cop, 0.0f);
+  std::vector<float> bias(cop < 48 ? 48 : cop, 0.0f);
   memcpy(bias.data(), conv_b, sizeof(float) * out_ch);
+  if (E == 128 && out_ch <= 48) {
+    // the 128 upsampled channels (conv input channels 32..159) as A fragments of v_mfma_f32_16x16x32_f16:
+    // [tap][k-step j][N tile nt][lane (row = lane & 15 -> output channel 16 nt + row, k = 32 j + 8 (lane >> 4) + e)][e]
+    std::vector<uint16_t> uh((size_t)9 * 4 * 3 * 64 * 8, 0), ul(uh.size(), 0);
+    for (int tap = 0; tap < 9; ++tap)
+      for (int j = 0; j < 4; ++j)
+        for (int nt2 = 0; nt2 < 3; ++nt2)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int e2 = 0; e2 < 8; ++e2) {
+              const int co = 16 * nt2 + (lane & 15), c = 32 + 32 * j + 8 * (lane >> 4) + e2;
+              if (co >= out_ch) continue;
+              const float v = conv_w[((size_t)co * CIN + c) * 9 + tap] * sc;
+              const size_t d = ((((size_t)tap * 4 + j) * 3 + nt2) * 64 + lane) * 8 + e2;
+              uh[d] = float_to_half(v);
+              ul[d] = float_to_half(v - half_to_float(uh[d]));
+            }
+    std::vector<uint16_t> sh((size_t)9 * 48 * 32, 0), sl(sh.size(), 0);
+    for (int co = 0; co < out_ch; ++co)
+      for (int c = 0; c < 32; ++c)
+        for (int tap = 0; tap < 9; ++tap) {
+          const float v = conv_w[((size_t)co * CIN + c) * 9 + tap] * sc;
+          const size_t d = ((size_t)tap * 48 + co) * 32 + c;
+          sh[d] = float_to_half(v);
+          sl[d] = float_to_half(v - half_to_float(sh[d]));
+        }
+    HIPCHK(hipMalloc(&h->ts_hi, sh.size() * 2));
+    HIPCHK(hipMalloc(&h->ts_lo, sl.size() * 2));
+    HIPCHK(hipMemcpy(h->ts_hi, sh.data(), sh.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->ts_lo, sl.data(), sl.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&h->tu_hi, uh.size() * 2));
+    HIPCHK(hipMalloc(&h->tu_lo, ul.size() * 2));
+    HIPCHK(hipMemcpy(h->tu_hi, uh.data(), uh.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->tu_lo, ul.data(), ul.size() * 2, hipMemcpyHostToDevice));
+  }
   HIPCHK(hipMalloc(&h->tl_hi, hi.size() * 2));
   HIPCHK(hipMalloc(&h->tl_lo, lo.size() * 2));
   HIPCHK(hipMalloc(&h->tl_bias, bias.size() * sizeof(float)));
@@ -1249,8 +1291,31 @@ int ita_fusion_tail_large(ita_handle h, const float* x, float* out, int batch, i
   if (!h->tl_hi) return fail(ITA_ERR_NO_WEIGHTS, "ita_fusion_tail_load has not been called");
   if (tok_h < 4 || tok_w < 16 || (2 * tok_h) % 8 || (2 * tok_w) % 32 || batch > 65535)
     return fail(ITA_ERR_UNSUPPORTED, "needs tok_h % 4 == 0, tok_w % 16 == 0, batch <= 65535");
-  ItaTailBigArgs a{x, h->tl_hi, h->tl_lo, h->tl_bias, h->tl_inv_scale, out, batch, h->tl_E, tok_h, tok_w, h->tl_CO, h->tl_nchunk};
+  ItaTailBigArgs a{x, h->tl_hi, h->tl_lo, h->tl_bias, h->tl_inv_scale, out, batch, h->tl_E, tok_h, tok_w, h->tl_CO, h->tl_nchunk, 0};
   hipStream_t s = (hipStream_t)stream;
+  // E = 128: the upsampled channels (4/5 of the contraction) by linearity on the low-resolution tokens (ita_tail_up_kernel),
+  // the pixel-shuffle channels (= chunk 0 of the implicit GEMM) added by ita_tail_big_kernel.  Needs whole 16 x 32 tiles and
+  // every tile's source region inside 10 x 18 tokens (same float expressions as the kernel; true for every x2 grid tried,
+  // checked instead of assumed).  ITA_TAIL_UP=0: the round-2 single-kernel path.
+  static const bool up_off = getenv("ITA_TAIL_UP") && atoi(getenv("ITA_TAIL_UP")) == 0;
+  if (h->tu_hi && !up_off && (2 * tok_h) % 16 == 0 && (2 * tok_w) % 32 == 0) {
+    const int OH = 2 * tok_h, OW = 2 * tok_w;
+    auto span_ok = [](int T, int O, int tile, int lim) {
+      const float sc = (float)(T - 1) / (float)(O - 1);
+      auto src = [&](int q) { int i = (int)(sc * (float)q); return i > T - 1 ? T - 1 : i; };
+      for (int t0 = 0; t0 < O; t0 += tile) {
+        const int lo = src(t0 - 1 < 0 ? 0 : t0 - 1), hq = src(t0 + tile > O - 1 ? O - 1 : t0 + tile);
+        if (hq + (hq < T - 1 ? 1 : 0) - lo > lim - 1) return false;
+      }
+      return true;
+    };
+    if (span_ok(tok_h, OH, 16, ItaTailUpLds::RH) && span_ok(tok_w, OW, 32, ItaTailUpLds::RW)) {
+      ItaTailUpArgs u{x, h->tu_hi, h->tu_lo, h->ts_hi, h->ts_lo, h->tl_bias, h->tl_inv_scale, out, batch, tok_h, tok_w, h->tl_CO};
+      hipLaunchKernelGGL(ita_tail_up_kernel, dim3(OW / 32, OH / 16, batch), dim3(512), ItaTailUpLds::TOTAL, s, u);
+      HIPCHK(hipGetLastError());
+      return ITA_OK;
+    }
+  }
   switch (h->tl_nt) {
     case 1: return launch_tail_big<1>(h, a, s);
     case 2: return launch_tail_big<2>(h, a, s);
