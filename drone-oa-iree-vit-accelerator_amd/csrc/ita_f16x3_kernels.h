@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64 * WM * WN) void ita_gemm_f16x3_kernel(const ItaG
 // workgroups).  Here a workgroup of four waves owns MT (1..4) 32-row M tiles x one 32-column
 // W tile x one K slice: wave w computes M tile w, ALL four waves issue the LDS-DMA of the next k-tiles (an LDS ring
 // of three 64-deep k-tiles).  grid.x = N/32 * nsplit with id % nsplit = the K slice (each XCD's L2 sees one
-// slice of A and of G0), grid.y = ceil(M / 128).
+// slice of A and of G0), grid.y = ceil(M / (32 MT)); the launcher picks MT (ita_plugin.hip: launch_gemm_split).
 // What this shape answers (all measured, 128 frames unless noted): a fragment is 16 bytes per lane at ROW r, so a
 // wave-load of fragments touches 32 cache lines for 32 bytes each and the load pipeline's per-instruction cost, not
 // bandwidth or latency, sets the pace -- one wave streaming its own tile into a register ring took 20 us whether its
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void ita_gemm_f16x3_small_kernel(const ItaGemm
   static_assert(NSTG == 3 && DMA < 64, "one younger k-tile in flight at the wait; vmcnt range");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
-  const int z = blockIdx.x % g.nsplit, n0 = (blockIdx.x / g.nsplit) * 32, m0 = blockIdx.y * 128;
+  const int z = blockIdx.x % g.nsplit, n0 = (blockIdx.x / g.nsplit) * 32, m0 = blockIdx.y * 32 * MT;
   const int kslice = g.K / g.nsplit, kbeg = z * kslice, nt = kslice / 64;
   auto stage = [&](int kt, int slot) {
     char* b = lds + slot * STG;

@@ -668,8 +668,17 @@ int launch_gemm_split(const _Float16* a_hi, const _Float16* a_lo, int lda, const
     return ITA_OK;
   }
   if (M <= small_max && N % 32 == 0) {   // a few M tiles: four-wave workgroups share the staging, same arithmetic
-    const dim3 grid((N / 32) * nsplit, (M + 127) / 128);
-    switch (M >= 128 ? 4 : (M + 31) / 32) {
+    // M tiles per workgroup: up to four (128 frames: 128 workgroups).  Fewer tiles per workgroup fill the chip -- MT = ceil(M / 64)
+    // gives 256 workgroups from 64 frames on and the kernel alone gets 1.4-2.9 us faster (64 / 128 frames, one stream) -- but in
+    // the three-branch graph schedule that bench.py uses at these sizes a 256-workgroup GEMM leaves no CU to the LSTM branch
+    // and the step gets SLOWER (128 frames: 36.6 -> 38.3 us).  Per output element the arithmetic does not depend on MT;
+    // ITA_GEMM_SMALL_MT forces one (A/B runs, one-stream hosts).
+    static const int mt_env = getenv("ITA_GEMM_SMALL_MT") ? atoi(getenv("ITA_GEMM_SMALL_MT")) : 0;
+    int mt = mt_env >= 1 && mt_env <= 4 ? mt_env : (M >= 128 ? 4 : (M + 31) / 32);
+    if (mt > 4) mt = 4;
+    if (mt < 1) mt = 1;
+    const dim3 grid((N / 32) * nsplit, (M + 32 * mt - 1) / (32 * mt));
+    switch (mt) {
       case 1: hipLaunchKernelGGL(ita_gemm_f16x3_small_kernel<1>, grid, dim3(256), ita_gemm_small_lds(1), s, g); break;
       case 2: hipLaunchKernelGGL(ita_gemm_f16x3_small_kernel<2>, grid, dim3(256), ita_gemm_small_lds(2), s, g); break;
       case 3: hipLaunchKernelGGL(ita_gemm_f16x3_small_kernel<3>, grid, dim3(256), ita_gemm_small_lds(3), s, g); break;
