@@ -20,6 +20,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
                 scalar int8 oracle (oracle/ita_oracle.c), one process per core and one core alone
   configs       c2: BASELINE config 2 (int8 MHA block alone: B = 1 latency, 1024-frame int8 MFMA fraction);
                 c5: BASELINE config 5 (fusion tail on a 64x128 token grid: MFMA and HBM fractions), same run (N = 1 only);
+                c5_mha: config 5 as worded, the int8 attention block on 8192 tokens per frame (three-sweep integer softmax);
                 vit2l: the second graph family (E = 128, two layers, no fusion tail), whole forward at 1024 frames;
                 b1 / b128 / b256: step time of the whole forward at 1, 128, 256 frames per GPU (config 3; config 4 cut over 8 GPUs)
 --schedule selects one stream / the library's two-stream pipeline / its HIP-graph form (default: graph up to 256 frames per GPU).
@@ -251,6 +252,41 @@ def bench_c5(frames=32, out_ch=48, iters=20):
             "hbm": {"achieved": round(byts / ms / 1e6, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(t_hbm / ms, 4)},
             "bound": "mfma" if t_mfma >= t_hbm else "hbm",
             "timing": f"torch events over {iters} back-to-back launches on the launch stream"}
+
+
+def bench_c5_mha(frames=32, seq=8192, iters=5):
+    """BASELINE config 5 as it is worded (480 x 720 input, 64x patch-token blow-up): the int8 attention block on seq = 8192
+    tokens per frame, E = 128 (ita_mha_long_q8: int8 codes in and out; three sweeps over the key tiles, Q K^T recomputed in each,
+    logits never materialised).  Algorithmic int8 ops per frame (one Q K^T, one A.V, projections):
+    2 * (2 * seq^2 * 192 + 4 * seq * 128 * 192); executed: three Q K^T."""
+    import torch
+    from drone_oa_iree_vit_accelerator_amd import host, params
+    d = params.load_fixture(os.path.join(REPO, "tests", "golden", "blocks_E128_seed0_B1.npz"))
+    eng = host.Engine(params.blob_from_record(d, None, E=128), device=torch.cuda.current_device())
+    g = torch.Generator(device="cpu").manual_seed(5)
+    base = torch.randn((frames, seq // 32, 128), generator=g).repeat_interleave(32, dim=1) * 18.0
+    xq = (base + torch.randn((frames, seq, 128), generator=g) * 9.0).round().clamp(-128, 127).to(torch.int8).cuda()
+    for _ in range(2):
+        eng.mha_long_q8(xq)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        eng.mha_long_q8(xq)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    eng.close()
+    ops = 2.0 * (2.0 * seq * seq * 192 + 4.0 * seq * 128 * 192) * frames
+    executed = 2.0 * (4.0 * seq * seq * 192 + 4.0 * seq * 128 * 192) * frames
+    return {"workload": f"int8 attention block on {seq} tokens per frame, E=128, {frames} frames (ita_mha_long_q8: int8 codes in / out)",
+            "kernels": "ita_long_proj_kernel, ita_long_attn_kernel", "dtype": "int8", "frames": frames, "seq_len": seq,
+            "ms_per_launch": round(ms, 4), "frames_per_s": round(frames / ms * 1e3, 1),
+            "mfma": {"achieved": round(ops / ms / 1e9, 1), "peak": 5000.0, "unit": "TOP/s", "frac": round(ops / ms / 1e9 / 5000.0, 4),
+                     "executed_frac": round(executed / ms / 1e9 / 5000.0, 4),
+                     "note": "algorithmic ops (one Q K^T); the three-sweep integer softmax executes Q K^T three times"},
+            "hbm_bytes_per_launch": int(frames * seq * (2 * 128 + 2 * 3 * 192)),
+            "timing": f"torch events over {iters} back-to-back calls on the launch stream"}
 
 
 def bench_vit2l(frames=1024, iters=50):
@@ -640,7 +676,7 @@ def main():
             # the other single-GPU configurations of BASELINE.json, measured in this same run
             del graph
             eng.close()
-            out["configs"] = {"c2": bench_c2(), "c5": bench_c5(), **bench_small(blob)}
+            out["configs"] = {"c2": bench_c2(), "c5": bench_c5(), "c5_mha": bench_c5_mha(), **bench_small(blob)}
             v2 = bench_vit2l()
             if v2:
                 out["configs"]["vit2l"] = v2

@@ -21,6 +21,7 @@
 #include "ita_f32_kernels.h"
 #include "ita_int8_kernels.h"
 #include "ita_stream_kernel.h"
+#include "ita_long_attn_kernel.h"
 
 namespace {
 
@@ -112,6 +113,9 @@ struct ita_context {
   float* tl_bias = nullptr;
   float tl_inv_scale = 1.0f;
   int tl_E = 0, tl_CO = 0, tl_nt = 0, tl_nchunk = 0;
+  // long-sequence attention (ita_mha_long_q8): Q fragments, K / V^T images, column sums; grown on demand
+  char* long_ws = nullptr;
+  size_t long_ws_bytes = 0;
   // staging for the host-buffer drop-in symbols
   float *dsp_in = nullptr, *dsp_out = nullptr;
   std::vector<float> dsp_host;
@@ -853,6 +857,10 @@ int ita_create(ita_handle* out, int device_ordinal) {
   if ((rc = set_lds(ita_tokenizer_kernel<128, false>, ita_tok_lds_bytes<128>()))) { delete c; return rc; }
   if ((rc = set_lds(ita_tail_kernel<64>, ita_tail_lds_bytes<64>()))) { delete c; return rc; }
   if ((rc = set_lds(ita_tail_up_kernel, ItaTailUpLds::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_long_proj_kernel<false>, ItaStreamLds<128, false, false>::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_long_proj_kernel<true>, ItaStreamLds<128, false, false>::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_long_attn_kernel<false>, ItaLongLds::TOTAL))) { delete c; return rc; }
+  if ((rc = set_lds(ita_long_attn_kernel<true>, ItaLongLds::TOTAL))) { delete c; return rc; }
   if ((rc = set_lds(ita_stream_kernel<64, true, 1, false, false, true>, ItaStreamLds<64, true, true>::TOTAL))) { delete c; return rc; }
   if ((rc = set_lds(ita_stream_kernel<64, true, 0, false, false, true>, ItaStreamLds<64, true, false>::TOTAL))) { delete c; return rc; }
   if ((rc = set_lds(ita_stream_kernel<64, false, 0, false, false, true>, ItaStreamLds<64, false, false>::TOTAL))) { delete c; return rc; }
@@ -896,6 +904,7 @@ int ita_destroy(ita_handle h) {
   for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->pipe_ev) (void)hipEventDestroy(e);
   if (h->pipe_h) (void)hipFree(h->pipe_h);
+  if (h->long_ws) (void)hipFree(h->long_ws);
   if (h->dsp_in) (void)hipFree(h->dsp_in);
   if (h->dsp_out) (void)hipFree(h->dsp_out);
   free_tail_large(h);
@@ -1145,6 +1154,47 @@ int ita_mha_int8_taps(ita_handle h, int layer, const float* x, float* y, int bat
 }
 int ita_mha_int8(ita_handle h, int layer, const float* x, float* y, int batch, void* stream) {
   return ita_mha_int8_taps(h, layer, x, y, batch, nullptr, stream);
+}
+
+int ita_mha_long_q8(ita_handle h, int layer, const int8_t* x_q, int8_t* out_q, int batch, int seq_len, void* stream) {
+  int rc = check(h, batch);
+  if (rc) return rc;
+  if (!x_q || !out_q || layer < 0 || layer >= h->hdr.num_layers) return fail(ITA_ERR_INVALID_ARG, "bad pointer or layer");
+  if (h->hdr.E != 128) return fail(ITA_ERR_UNSUPPORTED, "long-sequence attention is built for E = 128 (models/ITA, models/ITA_upsample_shuffle)");
+  if (seq_len < 128 || seq_len % 128 || seq_len > 65536 || batch > 65535)
+    return fail(ITA_ERR_UNSUPPORTED, "seq_len must be a multiple of 128 in [128, 65536], batch <= 65535");
+  const Layer& L = h->layers[layer];
+  if (!L.simg_mha) return fail(ITA_ERR_UNSUPPORTED, "this layer has no attention image (accumulator range)");
+  // the logits of a long row still fit the 16-bit travel format: same bound as stream_range_ok (per key, not per row)
+  hipStream_t s = (hipStream_t)stream;
+  const size_t ntile = (size_t)batch * (seq_len / 128);
+  const size_t need = ntile * (3 * 24576 + 192 * 4);
+  if (need > h->long_ws_bytes) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+      return fail(ITA_ERR_INVALID_ARG, "the long-attention workspace cannot grow inside a stream capture; run one call first");
+    HIPCHK(hipDeviceSynchronize());
+    if (h->long_ws) (void)hipFree(h->long_ws);
+    h->long_ws = nullptr; h->long_ws_bytes = 0;
+    HIPCHK(hipMalloc(&h->long_ws, need));
+    h->long_ws_bytes = need;
+  }
+  ItaLongArgs a{};
+  a.image = L.simg_mha; a.xq = x_q; a.yq = out_q;
+  a.qfrag = h->long_ws; a.kimg = a.qfrag + ntile * 24576; a.vimg = a.kimg + ntile * 24576;
+  a.csum = (int*)(a.vimg + ntile * 24576);
+  a.mq = L.ascal[ITA_A_MQ]; a.mk = L.ascal[ITA_A_MK]; a.mv = L.ascal[ITA_A_MV]; a.ml = L.ascal[ITA_A_ML];
+  a.mc = L.ascal[ITA_A_MC]; a.mo = L.ascal[ITA_A_MO];
+  a.B = batch; a.S = seq_len;
+  const bool fast = L.fast_sites == ITA_SITES_ALL;
+  const int pg = ntile < (size_t)h->num_cus ? (int)ntile : h->num_cus;
+  if (fast) hipLaunchKernelGGL(ita_long_proj_kernel<true>, dim3(pg), dim3(512), (ItaStreamLds<128, false, false>::TOTAL), s, a);
+  else hipLaunchKernelGGL(ita_long_proj_kernel<false>, dim3(pg), dim3(512), (ItaStreamLds<128, false, false>::TOTAL), s, a);
+  HIPCHK(hipGetLastError());
+  if (fast) hipLaunchKernelGGL(ita_long_attn_kernel<true>, dim3(seq_len / 128, batch), dim3(512), ItaLongLds::TOTAL, s, a);
+  else hipLaunchKernelGGL(ita_long_attn_kernel<false>, dim3(seq_len / 128, batch), dim3(512), ItaLongLds::TOTAL, s, a);
+  HIPCHK(hipGetLastError());
+  return ITA_OK;
 }
 
 int ita_mha_q8(ita_handle h, int layer, const int8_t* x_q, int8_t* out_q, int batch, void* stream) {

@@ -29,7 +29,7 @@ DISPATCH_F16, DISPATCH_F32 = 0, 1
 
 EXPORTED_SYMBOLS = (
     "ita_abi_version", "ita_create", "ita_destroy", "ita_load_weights", "ita_validate_blob", "ita_reserve", "ita_get_dims",
-    "ita_last_error", "ita_error_string", "ita_mha_int8", "ita_mha_int8_taps", "ita_mha_q8", "ita_ffn_int8", "ita_ffn_int8_taps",
+    "ita_last_error", "ita_error_string", "ita_mha_int8", "ita_mha_int8_taps", "ita_mha_q8", "ita_mha_long_q8", "ita_ffn_int8", "ita_ffn_int8_taps",
     "ita_encoder_layer", "ita_tokenizer", "ita_fusion_tail", "ita_vitlstm_forward", "ita_bind_dispatch",
     "ita_profile_begin", "ita_profile_begin_sampled", "ita_profile_end", "ita_set_tail_mode", "ita_debug_encoder_stamps",
     "ita_fusion_tail_load", "ita_fusion_tail_large",
@@ -120,6 +120,7 @@ def lib():
         L.ita_vitlstm_back.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp]
         L.ita_vitlstm_pipelined.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, i, i, vp, vp]
         L.ita_mha_q8.argtypes = [vp, i, vp, vp, i, vp]
+        L.ita_mha_long_q8.argtypes = [vp, i, vp, vp, i, i, vp]
         L.ita_vitlstm_tail.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, vp]
         L.ita_debug_softmax_rows.argtypes = [vp, vp, vp, i, vp]
         L.ita_validate_blob.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
@@ -342,6 +343,17 @@ class Engine:
         x_q = x_q.contiguous()
         out = torch.empty_like(x_q)
         _chk(lib().ita_mha_q8(self._h, layer, x_q.data_ptr(), out.data_ptr(), x_q.shape[0], _stream_ptr(self.device)))
+        return out
+
+    def mha_long_q8(self, x_q, layer: int = 0):
+        """attention block on int8 codes over a long sequence: x_q (B,S,E) int8, S a multiple of 128 -> out_q (B,S,E) int8
+        (ita_mha_long_q8; BASELINE config 5 as worded: S = 8192)"""
+        torch = _torch()
+        assert x_q.dtype == torch.int8 and x_q.is_cuda and x_q.dim() == 3 and x_q.shape[2] == self.E
+        x_q = x_q.contiguous()
+        out = torch.empty_like(x_q)
+        _chk(lib().ita_mha_long_q8(self._h, layer, x_q.data_ptr(), out.data_ptr(), x_q.shape[0], x_q.shape[1],
+                                   _stream_ptr(self.device)))
         return out
 
     def softmax_rows(self, logits):

@@ -95,6 +95,13 @@ int ita_mha_int8_taps(ita_handle h, int layer, const float* x_dev, float* y_dev,
  * Equal, byte for byte, to the x_q -> out_q taps of ita_mha_int8_taps. */
 int ita_mha_q8(ita_handle h, int layer, const int8_t* x_q_dev, int8_t* out_q_dev, int batch, void* stream);
 
+/* The same block on LONG token sequences: x_q, out_q (B, seq_len, E) s8 with seq_len a multiple of 128 (E = 128 graphs only) --
+ * BASELINE config 5 as it is worded (480 x 720 input, 64x patch-token blow-up: seq_len = 8192).  Same arithmetic as above
+ * (layers.py:106-123, ITA_softmax.py:51-61 over a row of seq_len logits); the logits are never materialised: three sweeps over
+ * the key tiles per query tile (row maximum, row sum, probabilities -> A.V), Q K^T recomputed in each.  Its Q / K / V^T
+ * workspace (3 x 192 bytes per token) belongs to the handle and grows on demand (not inside a stream capture). */
+int ita_mha_long_q8(ita_handle h, int layer, const int8_t* x_q_dev, int8_t* out_q_dev, int batch, int seq_len, void* stream);
+
 /* ITAFeedForward_QAT.forward (models/ITA/QAT/layers.py:61-75). */
 int ita_ffn_int8(ita_handle h, int layer, const float* x_dev, float* y_dev, int batch, void* stream);
 typedef struct ita_ffn_taps { int8_t *x_q, *h, *out_q; } ita_ffn_taps;

@@ -384,6 +384,42 @@ int ita_oracle_mha_q8(const int8_t* xq, int B, int S, int E, int P, const int8_t
   return 0;
 }
 
+/* Long sequences (BASELINE config 5 as worded: a 64x patch-token blow-up, S = 8192): the same block, but only the query rows a
+ * test asks for -- K and V are projected for every token (O(S)), logits / softmax / A.V / out_proj only for `rows` (O(n S)),
+ * so a sampled check of an S = 8192 frame takes a second instead of the half minute of the S x S form.  Same primitives, same
+ * arithmetic: out_q[i] is row rows[i] of ita_oracle_mha_q8's result (tests/test_oracle_golden.py checks that on S = 256). */
+int ita_oracle_mha_q8_rows(const int8_t* xq, int S, int E, int P, const int8_t* wq, const int32_t* bq, const int8_t* wk,
+                           const int32_t* bk, const int8_t* wv, const int32_t* bv, const int8_t* wo, const int32_t* bo,
+                           const float* scal, const int32_t* rows, int n, int8_t* out_q /* (n, E) */) {
+  int8_t* K = (int8_t*)malloc((size_t)S * P);
+  int8_t* V = (int8_t*)malloc((size_t)S * P);
+  int8_t* Q = (int8_t*)malloc((size_t)P);
+  int8_t* L = (int8_t*)malloc((size_t)S);
+  uint8_t* A = (uint8_t*)malloc((size_t)S);
+  int8_t* C = (int8_t*)malloc((size_t)P);
+  ita_oracle_linear_q(xq, S, E, P, wk, bk, scal[ITA_A_MK], 0, K);
+  ita_oracle_linear_q(xq, S, E, P, wv, bv, scal[ITA_A_MV], 0, V);
+  for (int i = 0; i < n; ++i) {
+    const int r = rows[i];
+    if (r < 0 || r >= S) { free(K); free(V); free(Q); free(L); free(A); free(C); return -1; }
+    ita_oracle_linear_q(xq + (size_t)r * E, 1, E, P, wq, bq, scal[ITA_A_MQ], 0, Q);
+    for (int j = 0; j < S; ++j) {
+      int32_t acc = 0;
+      for (int d = 0; d < P; ++d) acc += (int32_t)Q[d] * (int32_t)K[(size_t)j * P + d];
+      L[j] = requant(acc, scal[ITA_A_ML]);
+    }
+    ita_oracle_softmax(L, 1, S, A);
+    for (int d = 0; d < P; ++d) {
+      int32_t acc = 0;
+      for (int j = 0; j < S; ++j) acc += (int32_t)A[j] * (int32_t)V[(size_t)j * P + d];
+      C[d] = requant(acc, scal[ITA_A_MC]);
+    }
+    ita_oracle_linear_q(C, 1, P, E, wo, bo, scal[ITA_A_MO], 0, out_q + (size_t)i * E);
+  }
+  free(K); free(V); free(Q); free(L); free(A); free(C);
+  return 0;
+}
+
 /* ITAFeedForward_QAT.forward */
 int ita_oracle_ffn(const float* x, int B, int S, int E, int F, const int8_t* w1, const int32_t* b1,
                    const int8_t* w2, const int32_t* b2, const float* scal, float* out_f, int8_t* t_xq,

@@ -117,6 +117,21 @@ def mha_q8(x_q, t, i=0):
     return out
 
 
+def mha_q8_rows(x_q, t, rows, i=0):
+    """rows `rows` of mha_q8's result for ONE frame x_q (S,E) int8 of any length S (ita_oracle_mha_q8_rows): (n,E) int8"""
+    x_q = _c(x_q, np.int8)
+    S, E = x_q.shape
+    P = t[f"attn{i}.wq"].shape[0]
+    rows = _c(rows, np.int32)
+    out = np.empty((len(rows), E), np.int8)
+    rc = lib().ita_oracle_mha_q8_rows(_p(x_q), S, E, P, _p(t[f"attn{i}.wq"]), _p(t[f"attn{i}.bq"]), _p(t[f"attn{i}.wk"]),
+                                      _p(t[f"attn{i}.bk"]), _p(t[f"attn{i}.wv"]), _p(t[f"attn{i}.bv"]), _p(t[f"attn{i}.wo"]),
+                                      _p(t[f"attn{i}.bo"]), _p(t[f"attn{i}.scal"]), _p(rows), len(rows), _p(out))
+    if rc:
+        raise RuntimeError(f"ita_oracle_mha_q8_rows rc={rc}")
+    return out
+
+
 def ffn(x, t, i=0, taps=False):
     x = _c(x, np.float32)
     B, S, E = x.shape

@@ -632,3 +632,54 @@ def test_full_size_properties_f32_frames(torch_cuda, oracle):
     np.testing.assert_allclose(v1.cpu().numpy()[sel], ov, atol=2e-5, rtol=0)
     np.testing.assert_allclose(c1.cpu().numpy()[:, sel], oc, atol=2e-5, rtol=0)
     eng.close()
+
+
+def _long_inputs(seed, B, S, E=128):
+    rs = np.random.RandomState(seed)
+    base = rs.standard_normal((B, S // 32, E)).repeat(32, axis=1) * 18.0
+    x = base + rs.standard_normal((B, S, E)) * 9.0
+    return np.clip(np.rint(x), -128, 127).astype(np.int8)
+
+
+@pytest.mark.parametrize("S,B", [(128, 3), (256, 2), (1024, 2), (2048, 1)])
+def test_long_sequence_attention_equals_oracle(torch_cuda, oracle, S, B):
+    """ita_mha_long_q8 (three sweeps over key tiles, logits never materialised) against the oracle's S x S form, bit for bit;
+    at S = 128 also against ita_mha_q8, the single-tile stream kernel."""
+    torch = torch_cuda
+    for fixture in ("blocks_E128_seed0_B1.npz", "blocks_E128_seed1_B1.npz"):   # seed 0: single-rounding form, seed 1: exact form
+        d = params.load_fixture(golden_files(fixture)[0])
+        eng, _, _ = _engine(d, 128, with_float=False)
+        t = _block_tensors(d)
+        xq = _long_inputs(S + B, B, S)
+        got = eng.mha_long_q8(torch.from_numpy(xq).cuda()).cpu().numpy()
+        want = oracle.mha_q8(xq, t)
+        np.testing.assert_array_equal(got, want)
+        assert len({r.tobytes() for r in got[0]}) > S // 4
+        if S == 128:
+            np.testing.assert_array_equal(eng.mha_q8(torch.from_numpy(xq).cuda()).cpu().numpy(), want)
+        eng.close()
+
+
+def test_long_sequence_attention_config5_size(torch_cuda, oracle):
+    """BASELINE config 5 as worded: S = 8192 tokens.  Sampled oracle rows (ita_oracle_mha_q8_rows: K, V for all tokens,
+    softmax and A.V for the sampled queries), run-to-run determinism, independence of a frame from its batch position; and
+    rows whose logits are all equal (probabilities underflow to 0: the context is 0 and out_proj gives its bias codes)."""
+    torch = torch_cuda
+    d = params.load_fixture(golden_files("blocks_E128_seed0_B1.npz")[0])
+    eng, _, _ = _engine(d, 128, with_float=False)
+    t = _block_tensors(d)
+    S, B = 8192, 2
+    xq = _long_inputs(99, B, S)
+    xq[1, 4096:] = 0                                   # half of frame 1: identical tokens
+    x = torch.from_numpy(xq).cuda()
+    a1 = eng.mha_long_q8(x)
+    a2 = eng.mha_long_q8(x)
+    sw = eng.mha_long_q8(x.flip(0).contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(a1, a2) and torch.equal(a1, sw.flip(0))
+    got = a1.cpu().numpy()
+    rows = [0, 1, 127, 128, 4095, 4096, 5000, 8191]
+    for b in range(B):
+        np.testing.assert_array_equal(got[b][rows], oracle.mha_q8_rows(xq[b], t, rows), err_msg=f"frame {b}")
+    assert len({r.tobytes() for r in got[0][::64]}) > 32
+    eng.close()

@@ -129,6 +129,36 @@ def test_attention_block_int8_entry(oracle, path):
     np.testing.assert_array_equal(got[rows_ok], d["s0.attn0.out_q"][rows_ok])
 
 
+def _long_inputs(seed, B, S, E=128):
+    """int8 block inputs for long-sequence attention tests: smooth low-frequency token content + noise, moderate range, so
+    that rows have a few dominant keys (non-trivial probabilities) at every S"""
+    rs = np.random.RandomState(seed)
+    base = rs.standard_normal((B, S // 32, E)).repeat(32, axis=1) * 18.0
+    x = base + rs.standard_normal((B, S, E)) * 9.0
+    return np.clip(np.rint(x), -128, 127).astype(np.int8)
+
+
+def test_long_attention_rows_entry(oracle):
+    """ita_oracle_mha_q8_rows (the checker of ita_mha_long_q8 at S = 8192: selected query rows only) against the S x S
+    form ita_oracle_mha_q8 on S = 384 -- identical rows -- and the softmax over a 384-long row against its definition."""
+    d = params.load_fixture(golden_files("blocks_E128_seed0_B1.npz")[0])
+    t = params.attention_tensors(d, "attn0.", 0)
+    xq = _long_inputs(3, 1, 384)
+    full = oracle.mha_q8(xq, t)
+    rows = [0, 1, 127, 128, 200, 383]
+    np.testing.assert_array_equal(oracle.mha_q8_rows(xq[0], t, rows), full[0][rows])
+    assert len({r.tobytes() for r in full[0]}) > 300                      # the rows really differ: attention is not degenerate here
+    lg = np.random.RandomState(1).randint(-128, 128, size=(3, 384)).astype(np.int8)
+    lg[1] = 100                                                           # 384 equal logits: sum = 384 * 256, inv = 170, p = 0
+    pr = oracle.softmax(lg)
+    for r in range(3):
+        sh = (lg[r].max().astype(int) - lg[r].astype(int))
+        num = np.where(sh > 31, 0, 256 >> np.minimum(sh, 31))
+        inv = int(np.floor(np.float32(1.0) / np.float32(max(num.sum(), 1)) * np.float32(16711680.0)))
+        np.testing.assert_array_equal(pr[r], (num * inv) >> 16)
+    assert pr[1].max() == 0
+
+
 @pytest.mark.parametrize("path", FIX_ALL, ids=_ids(FIX_ALL))
 def test_ffn_block(oracle, path):
     d = params.load_fixture(path)
