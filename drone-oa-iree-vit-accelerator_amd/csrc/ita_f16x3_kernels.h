@@ -779,11 +779,22 @@ struct ItaTailUpLds {
   static constexpr int WPL = 4 * 3 * 1024;                   // bytes per weight plane and tap
   static constexpr int W = 2 * YB;                           // two buffers x (hi | lo)
   static constexpr int TOTAL1 = W + 2 * 2 * WPL;             // phase 1: two Y slabs + two weight buffers
-  static constexpr int TOTAL2 = 2 * (18 * 34 * 64) + 2 * (9 * 48 * 64);   // phase 2: shuffle halo hi | lo, its weights hi | lo (>= U [48][516] f32)
-  static constexpr int TOTAL = TOTAL1 > TOTAL2 ? TOTAL1 : TOTAL2;
-  static_assert(48 * 516 * 4 <= TOTAL2 && TOTAL <= 160 * 1024, "LDS budget");
+  // phase 2: shuffle halo hi | lo at 0 (over the Y slabs); its weights sit at the END of the 160 KB so that they can be staged
+  // while phase 1 still runs: the lo plane lies wholly behind phase 1's LDS, the hi plane overlaps weight buffer 1 only (free
+  // once GEMM(7) is done)
+  static constexpr int HP = 18 * 34, A_PLANE = HP * 64, W2_PLANE = 9 * 48 * 64;
+  static constexpr int TOTAL = 160 * 1024;
+  static constexpr int WL2 = TOTAL - W2_PLANE, WH2 = WL2 - W2_PLANE;
+  static_assert(WL2 >= TOTAL1 && WH2 >= W + 2 * WPL && 2 * A_PLANE <= WH2 && 48 * 516 * 4 <= WH2, "phase-2 LDS");
 };
 
+#ifdef ITA_UP_STAMP
+// diagnostic build only (tools/tail_up_stamps.py): s_memrealtime (100 MHz) of every wave at the phase boundaries (<= 2048 workgroups)
+__device__ unsigned long long ita_up_stamp_buf[2048 * 8 * 12];
+#define ITA_UP_ST(i) do { if (lane == 0) ita_up_stamp_buf[((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave) * 12 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ITA_UP_ST(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void ita_tail_up_kernel(const ItaTailUpArgs a) {
   using L = ItaTailUpLds;
   constexpr int E = 128;
@@ -816,6 +827,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                        (__attribute__((address_space(3))) void*)(lds + L::W + buf * 2 * L::WPL + piece * 1024), 16, 0, 0);
     }
   };
+  ITA_UP_ST(0);
+  auto stage_w2 = [&](const _Float16* g, int dst) {
+    for (int wc = wave; wc < L::W2_PLANE / 1024; wc += 8)     // 27 pieces per plane
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (wc * 64 + lane) * 8),
+                                       (__attribute__((address_space(3))) void*)(lds + dst + wc * 1024), 16, 0, 0);
+  };
   stage_w(0);
 
   // ---- this wave's token tiles as B fragments (column = token, k = 8 (lane >> 4) .. + 7 of each 32-channel k-step), f16 hi / lo
@@ -832,8 +849,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         _Float16 h, l;
-        split_f16(v0[e], h, l); xh[m][j][e] = h; xl[m][j][e] = l;
-        split_f16(v1[e], h, l); xh[m][j][4 + e] = h; xl[m][j][4 + e] = l;
+        // element 2 e <-> channel offset e, element 2 e + 1 <-> offset 4 + e (the weight image uses the same order): dword e of a
+        // fragment is then the channel pair (c, c + 1) of pixel-shuffle parity e -- phase 2 writes it to its halo as it is
+        split_f16(v0[e], h, l); xh[m][j][2 * e] = h; xl[m][j][2 * e] = l;
+        split_f16(v1[e], h, l); xh[m][j][2 * e + 1] = h; xl[m][j][2 * e + 1] = l;
       }
     }
   }
@@ -915,11 +934,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   };
 
+  ITA_UP_ST(1);
 #pragma unroll 1
   for (int t = 0; t < 9; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of W[t] have landed
     __syncthreads();                                   // W[t] complete; GEMM(t-1) done by every wave: Y[(t-1)&1] complete, W[(t+1)&1] free; blend(t-2) done: Y[t&1] free
     if (t + 1 < 9) stage_w(t + 1);
+    if (t == 0) stage_w2(a.s_lo, L::WL2);                // phase 2's weights: lo plane now, hi plane once weight buffer 1 is free
+    if (t == 8) stage_w2(a.s_hi, L::WH2);
 #ifndef ITA_UP_ABLATE
 #define ITA_UP_ABLATE 0
 #endif
@@ -928,66 +950,61 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   __syncthreads();
   if (!(ITA_UP_ABLATE & 2)) blend(8);
+  ITA_UP_ST(2);
 
-  // ================= phase 2: the E/4 pixel-shuffle channels -- a plain gather of token channels, no interpolation -- as an
-  // implicit GEMM on the 18 x 34 halo of this tile (ita_tail_big_kernel's chunk 0, same fragments and weights), then both
-  // parts meet in LDS and leave as 16-byte stores.  Phase 1's LDS is dead: [halo hi | halo lo | weights hi | weights lo].
+  // ================= phase 2: the E/4 pixel-shuffle channels -- PixelShuffle(2): out[c][2h+i][2w+j] = in[4c+2i+j][h][w], a plain
+  // regrouping of token channels, no interpolation -- as an implicit GEMM on the 18 x 34 halo of this tile, then both parts
+  // meet in LDS and leave as 16-byte stores.  The halo comes from the token fragments this wave already holds (f16 hi / lo,
+  // dword e of a fragment = channels (c, c + 1) of parity e): one ds_write_b32 per dword, no second trip to memory.
+  // Pixel hp's 64 bytes hold its 32 channels as four 16-byte chunks, chunk q at position q ^ ((hp >> 2) & 3) (conflict-free
+  // fragment reads, 2-way writes).  Phase 1's Y slabs are dead: [halo hi | halo lo] over them.
   __syncthreads();
   {
-    constexpr int HP = 18 * 34, A_PLANE = HP * 64, W_PLANE = 9 * 48 * 64;
-    constexpr int AH = 0, AL = A_PLANE, WH = 2 * A_PLANE, WL = WH + W_PLANE;
-    static_assert(WL + W_PLANE <= L::TOTAL2, "phase-2 LDS");
-    for (int wc = wave; wc < W_PLANE / 1024; wc += 8) {     // 27 pieces per plane
-      const int piece = wc * 64 + lane;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.s_hi + piece * 8),
-                                       (__attribute__((address_space(3))) void*)(lds + WH + wc * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.s_lo + piece * 8),
-                                       (__attribute__((address_space(3))) void*)(lds + WL + wc * 1024), 16, 0, 0);
+    constexpr int HP = L::HP, A_PLANE = L::A_PLANE;
+    constexpr int AH = 0, AL = A_PLANE, WH = L::WH2, WL = L::WL2;
+    // halo pixels outside the image (the conv's zero padding): no token writes them
+    for (int i0 = tid; i0 < HP * 8; i0 += 512) {
+      const int p = i0 >> 3, hy = p / 34, hx = p - 34 * hy;
+      const int y = ty0 + hy - 1, x = tx0 + hx - 1;
+      if (y < 0 || y >= OH || x < 0 || x >= OW) *(f32x4*)(lds + p * 64 + (i0 & 4 ? AL : AH) + (i0 & 3) * 16) = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     }
-    // halo of the shuffled map: PixelShuffle(2): out[c][2h+i][2w+j] = in[4c+2i+j][h][w]; item = (pixel, 4 channels), ten items
-    // per thread with EVERY global load issued (from clamped, always valid addresses) before the first use: one memory latency
-    // for the tile instead of one per item
-    {
-      constexpr int NIT = (HP * 8 + 511) / 512;
-      float v[NIT][4];
-      bool okv[NIT];
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int i0 = min(tid + 512 * it, HP * 8 - 1);
-        const int p = i0 >> 3, cq = i0 & 7;
-        const int hy = p / 34, hx = p - 34 * hy;
-        const int y = ty0 + hy - 1, x = tx0 + hx - 1;
-        okv[it] = y >= 0 && y < OH && x >= 0 && x < OW;
-        const int yc = min(max(y, 0), OH - 1), xc = min(max(x, 0), OW - 1);
-        const float* t = xt + ((size_t)(yc >> 1) * a.TW + (xc >> 1)) * E + 2 * (yc & 1) + (xc & 1) + 16 * cq;
+    for (int m = 0; m < 2; ++m) {
+      if (m < nmt) {
+        const int slot = 16 * (wave + 8 * m) + (lane & 15);
+        const int r = slot / L::RW, c = slot - L::RW * r;
+        const int th_ = ry0 + r, tw_ = rx0 + c;                                        // (clamped copies beyond the grid: skipped)
+        const bool tok_ok = slot < L::RH * L::RW && th_ < a.TH && tw_ < a.TW;
+        const int hy0 = 2 * th_ - (ty0 - 1), hx0 = 2 * tw_ - (tx0 - 1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[it][j] = t[4 * j];
-      }
+        for (int par = 0; par < 4; ++par) {
+          const int hy = hy0 + (par >> 1), hx = hx0 + (par & 1);
+          if (tok_ok && hy >= 0 && hy < 18 && hx >= 0 && hx < 34) {
+            const int hp = hy * 34 + hx;
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int i0 = tid + 512 * it;
-        if (i0 < HP * 8) {
-          const int p = i0 >> 3, cq = i0 & 7;
-          f16x4 vh, vl;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            _Float16 hq, lq;
-            split_f16(okv[it] ? v[it][j] : 0.0f, hq, lq);
-            vh[j] = hq; vl[j] = lq;
+            for (int j = 0; j < 4; ++j) {
+              const int off = hp * 64 + ((j ^ ((hp >> 2) & 3)) << 4) + 4 * (lane >> 4);
+              *(int*)(lds + AH + off) = __builtin_bit_cast(i32x4, xh[m][j])[par];
+              *(int*)(lds + AL + off) = __builtin_bit_cast(i32x4, xl[m][j])[par];
+            }
           }
-          *(f16x4*)(lds + AH + p * 64 + cq * 8) = vh;
-          *(f16x4*)(lds + AL + p * 64 + cq * 8) = vl;
         }
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    ITA_UP_ST(3);
     f32x4 acc2[4][3];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 3; ++nt) acc2[mt][nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     const int pxl = lane & 15, kg = lane >> 4;
+    // the three biases of this lane's output channels: requested here, used behind the MFMA loop (a load at the point of use
+    // waits 8 us behind the other workgroups' output stores -- tools/tail_up_stamps.py)
+    float bco[3];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) bco[nt] = a.bias[nt * 16 + pxl];
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
       const int ky = tap / 3, kx = tap - 3 * ky;
@@ -1001,8 +1018,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const int hp = (2 * wave + (mt >> 1) + ky) * 34 + (mt & 1) * 16 + pxl + kx;
-        const f16x8 ah = *(const f16x8*)(lds + AH + hp * 64 + kg * 16);
-        const f16x8 al = *(const f16x8*)(lds + AL + hp * 64 + kg * 16);
+        const int ao = hp * 64 + ((kg ^ ((hp >> 2) & 3)) << 4);
+        const f16x8 ah = *(const f16x8*)(lds + AH + ao);
+        const f16x8 al = *(const f16x8*)(lds + AL + ao);
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt) {
           acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[nt], acc2[mt][nt], 0, 0, 0);
@@ -1011,13 +1029,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
       }
     }
+    ITA_UP_ST(4);
     __syncthreads();       // halo and weights consumed: the interpolated part moves into LDS as U[co][pixel] (row stride 516)
+    ITA_UP_ST(8);
     float* U = (float*)lds;
 #pragma unroll
     for (int g = 0; g < 12; ++g)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) U[(4 * g + i) * 516 + tid] = acc[g][i] * a.inv_wscale + a.bias[4 * g + i];
+      for (int i = 0; i < 4; ++i) U[(4 * g + i) * 516 + tid] = acc[g][i];   // (raw: a VALU temporary between the stores serialises them -- each multiply waited for the previous ds_write to have read its operand, 8 us for the 48)
+    ITA_UP_ST(9);
     __syncthreads();
+    ITA_UP_ST(7);
     // C layout of phase 2: lane = (output channel 16 nt + lane & 15, pixels 4 (lane >> 4) .. + 3 of M tile mt): 16-byte stores
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -1029,10 +1051,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           const f32x4 u = *(const f32x4*)(U + co * 516 + row * 32 + col);
           f32x4 o;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) o[i] = u[i] + acc2[mt][nt][i] * a.inv_wscale;
+          for (int i = 0; i < 4; ++i) o[i] = (u[i] * a.inv_wscale + bco[nt]) + acc2[mt][nt][i] * a.inv_wscale;
           *(f32x4*)(a.out + (((size_t)b * a.CO + co) * OH + ty0 + row) * OW + tx0 + col) = o;
         }
       }
     }
+    ITA_UP_ST(5);
+#ifdef ITA_UP_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ITA_UP_ST(6);
+#endif
   }
 }

@@ -1236,6 +1236,13 @@ int ita_debug_encoder_stamps(ita_handle h, int layer, const float* x, const void
                         nullptr, image_u8);
 }
 
+#ifdef ITA_UP_STAMP
+// diagnostic build only: the phase stamps of the last ita_tail_up_kernel launch ([workgroup][wave 0 | 4][8] x u64)
+int ita_debug_tail_up_stamps(unsigned long long* host_dst, int count) {
+  if (hipDeviceSynchronize() != hipSuccess) return ITA_ERR_HIP;
+  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(ita_up_stamp_buf), sizeof(unsigned long long) * (size_t)count) == hipSuccess ? ITA_OK : ITA_ERR_HIP;
+}
+#endif
 int ita_debug_softmax_rows(ita_handle h, const int8_t* logits, uint8_t* probs, int rows, void* stream) {
   int rc = check(h, rows, false);
   if (rc) return rc;
@@ -1300,14 +1307,16 @@ int ita_fusion_tail_load(ita_handle h, const float* conv_w, const float* conv_b,
   memcpy(bias.data(), conv_b, sizeof(float) * out_ch);
   if (E == 128 && out_ch <= 48) {
     // the 128 upsampled channels (conv input channels 32..159) as A fragments of v_mfma_f32_16x16x32_f16:
-    // [tap][k-step j][N tile nt][lane (row = lane & 15 -> output channel 16 nt + row, k = 32 j + 8 (lane >> 4) + e)][e]
+    // [tap][k-step j][N tile nt][lane (row = lane & 15 -> output channel 16 nt + row, k = 32 j + 8 (lane >> 4) + o(e))][e],
+    // o(e) = 4 (e & 1) + (e >> 1): the element order of the kernel's token fragments (dword p of a fragment = the channel pair
+    // of pixel-shuffle parity p)
     std::vector<uint16_t> uh((size_t)9 * 4 * 3 * 64 * 8, 0), ul(uh.size(), 0);
     for (int tap = 0; tap < 9; ++tap)
       for (int j = 0; j < 4; ++j)
         for (int nt2 = 0; nt2 < 3; ++nt2)
           for (int lane = 0; lane < 64; ++lane)
             for (int e2 = 0; e2 < 8; ++e2) {
-              const int co = 16 * nt2 + (lane & 15), c = 32 + 32 * j + 8 * (lane >> 4) + e2;
+              const int co = 16 * nt2 + (lane & 15), c = 32 + 32 * j + 8 * (lane >> 4) + 4 * (e2 & 1) + (e2 >> 1);
               if (co >= out_ch) continue;
               const float v = conv_w[((size_t)co * CIN + c) * 9 + tap] * sc;
               const size_t d = ((((size_t)tap * 4 + j) * 3 + nt2) * 64 + lane) * 8 + e2;
@@ -1365,6 +1374,9 @@ int ita_fusion_tail_large(ita_handle h, const float* x, float* out, int batch, i
       for (int t0 = 0; t0 < O; t0 += tile) {
         const int lo = src(t0 - 1 < 0 ? 0 : t0 - 1), hq = src(t0 + tile > O - 1 ? O - 1 : t0 + tile);
         if (hq + (hq < T - 1 ? 1 : 0) - lo > lim - 1) return false;
+        // the pixel-shuffle halo takes its tokens (q >> 1) from the same region
+        const int q0 = t0 - 1 < 0 ? 0 : t0 - 1, q1 = t0 + tile > O - 1 ? O - 1 : t0 + tile;
+        if ((q0 >> 1) < lo || (q1 >> 1) - lo > lim - 1) return false;
       }
       return true;
     };

@@ -65,8 +65,10 @@ def _run(torch, c, th, tw):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(128, 4, 16, 48, 2), (64, 8, 16, 9, 3), (128, 8, 32, 16, 1), (64, 4, 16, 33, 2)],
-                         ids=["E128_4x16_co48", "E64_8x16_co9", "E128_8x32_co16", "E64_4x16_co33"])
+@pytest.mark.parametrize("shape", [(128, 4, 16, 48, 2), (64, 8, 16, 9, 3), (128, 8, 32, 16, 1), (64, 4, 16, 33, 2),
+                                   (128, 24, 48, 48, 1), (128, 16, 16, 20, 2)],
+                         ids=["E128_4x16_co48", "E64_8x16_co9", "E128_8x32_co16", "E64_4x16_co33",
+                              "E128_24x48_co48_interior_tiles", "E128_16x16_co20_one_tile_wide"])
 def test_gpu_tail_large_vs_oracle(oracle, shape):
     import torch
     E, th, tw, co, B = shape
