@@ -20,6 +20,7 @@
 //                                  its input projection), adds the [h | desvel | quat] remainder, cell update
 //   ita_lstm_layer_kernel<NK>      LSTM layers 1, 2: [x | h] GEMM fused with the cell update
 #pragma once
+#include <type_traits>
 #include "ita_device.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -788,6 +789,12 @@ struct ItaTailUpLds {
   static_assert(WL2 >= TOTAL1 && WH2 >= W + 2 * WPL && 2 * A_PLANE <= WH2 && 48 * 516 * 4 <= WH2, "phase-2 LDS");
 };
 
+#ifndef ITA_UP_NB
+#define ITA_UP_NB 3
+#endif
+#ifndef ITA_UP_PKFMA
+#define ITA_UP_PKFMA 0
+#endif
 #ifdef ITA_UP_STAMP
 // diagnostic build only (tools/tail_up_stamps.py): s_memrealtime (100 MHz) of every wave at the phase boundaries (<= 2048 workgroups)
 __device__ unsigned long long ita_up_stamp_buf[2048 * 8 * 12];
@@ -835,12 +842,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   };
   stage_w(0);
 
-  // ---- this wave's token tiles as B fragments (column = token, k = 8 (lane >> 4) .. + 7 of each 32-channel k-step), f16 hi / lo
-  const int nmt = wave < 4 ? 2 : 1;
+  // ---- this wave's token tiles as B fragments (column = token, k = the 8 channels 32 j + 8 (lane >> 4) .. + 7 of each k-step), f16 hi / lo.
+  // 12 M tiles of 16 tokens x 3 N tiles = 36 units for 8 waves: wave w owns tile w (three units) and shares tile 8 + (w & 3)
+  // with its SIMD partner w ^ 4 -- waves 0..3 take its N tiles 0 and 1, waves 4..7 N tile 2 (and compute N tile 1 once more
+  // so that all waves run the same straight-line code; that copy is not stored): 5 / 4 units instead of 6 / 3
+  const bool heavy = wave < 4;
+  const int nt3 = heavy ? 0 : 2;
   f16x8 xh[2][4], xl[2][4];
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
-    const int slot = min(16 * (wave + 8 * m) + (lane & 15), L::RH * L::RW - 1);   // (slots 180..191 and the light waves' second tile: unused copies)
+    const int slot = min(16 * (m ? 8 + (wave & 3) : wave) + (lane & 15), L::RH * L::RW - 1);   // (slots 180..191: unused copies)
     const int r = slot / L::RW, c = slot - L::RW * r;
     const float* tp = xt + ((size_t)min(ry0 + r, a.TH - 1) * a.TW + min(rx0 + c, a.TW - 1)) * E + 8 * (lane >> 4);
 #pragma unroll
@@ -857,99 +868,144 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
 
-  // ---- geometry of this thread's output pixel: source rows for dy = -1, 0, 1 and source columns for dx = -1, 0, 1
+  // ---- this thread's output pixel (its source rows / columns and weights are recomputed per tap: 30 instructions against 96
+  // packed FMAs, and 24 registers fewer across the loop)
   const int py = ty0 + (tid >> 5), px = tx0 + (tid & 31);
-  int rowo[3], colo[3], ypo[3], xpo[3];      // Y-slab float offset of the row / column, offset of the second row / column
-  float h1v[3], w1v[3], vy[3], vx[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    int i0, ip; float l1;
-    const int qy = py + d - 1, qx = px + d - 1;
-    src(min(max(qy, 0), OH - 1), sy, a.TH, i0, ip, l1);
-    rowo[d] = (i0 - ry0) * L::RW * L::YLD; ypo[d] = ip * L::RW * L::YLD; h1v[d] = l1; vy[d] = (qy >= 0 && qy < OH) ? 1.0f : 0.0f;
-    src(min(max(qx, 0), OW - 1), sx, a.TW, i0, ip, l1);
-    colo[d] = (i0 - rx0) * L::YLD; xpo[d] = ip * L::YLD; w1v[d] = l1; vx[d] = (qx >= 0 && qx < OW) ? 1.0f : 0.0f;
-  }
   f32x4 acc[12];
 #pragma unroll
   for (int g = 0; g < 12; ++g) acc[g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
-  auto gemm = [&](int t) {
+  // One tap step = GEMM(t) and blend(t - 1) of this wave as ONE software pipeline over the four k-steps: the LDS reads of
+  // k-step j + 1 (weight fragments) and of blend groups 3 j + 3 .. 3 j + 5 (Y rows) are in flight while the MFMAs of k-step j
+  // issue and the FMAs of groups 3 j .. 3 j + 2 run; sched_barriers pin that order (left alone hipcc runs the GEMM, then the
+  // blend with a wait per group: 6.9 k cycles per tap against 1.7 k of MFMA).  A wave can have 16 LDS instructions in flight.
+  auto tap = [&](auto G_, auto B_, const int t) {
+    constexpr bool DO_G = decltype(G_)::value, DO_B = decltype(B_)::value;
     const char* wb = lds + L::W + (t & 1) * 2 * L::WPL;
-    float* ys = (float*)(lds + L::Y + (t & 1) * L::YB);
-    f32x4 c[2][3];
+    float* ysw = (float*)(lds + L::Y + (t & 1) * L::YB);
+    // blend(t - 1): the four Y rows and weights of this thread's pixel
+    const int tb = t - 1, dy = tb / 3, dx = tb - 3 * dy;
+    const float* p00 = nullptr; const float* p01 = nullptr; const float* p10 = nullptr; const float* p11 = nullptr;
+    f32x4 q00 = {}, q01 = {}, q10 = {}, q11 = {};
+    if (DO_B) {
+      const float* ysr = (const float*)(lds + L::Y + (tb & 1) * L::YB);
+      const int qy = py + dy - 1, qx = px + dx - 1;
+      int r0, rp, c0, cp; float h1, w1;
+      src(min(max(qy, 0), OH - 1), sy, a.TH, r0, rp, h1);
+      src(min(max(qx, 0), OW - 1), sx, a.TW, c0, cp, w1);
+      const float ok = (qy >= 0 && qy < OH && qx >= 0 && qx < OW) ? 1.0f : 0.0f;   // 0: the tap's position lies in the conv's zero padding
+      const float h0 = 1.0f - h1, w0 = 1.0f - w1;
+      const float k00 = ok * (h0 * w0), k01 = ok * (h0 * w1), k10 = ok * (h1 * w0), k11 = ok * (h1 * w1);
+      q00 = (f32x4){k00, k00, k00, k00}; q01 = (f32x4){k01, k01, k01, k01}; q10 = (f32x4){k10, k10, k10, k10}; q11 = (f32x4){k11, k11, k11, k11};
+      p00 = ysr + ((r0 - ry0) * L::RW + (c0 - rx0)) * L::YLD;
+      p01 = p00 + cp * L::YLD;
+      p10 = p00 + rp * L::RW * L::YLD;
+      p11 = p10 + cp * L::YLD;
+    }
+    f32x4 c[5];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int u = 0; u < 5; ++u) c[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    // weight fragments of one k-step, N tiles in the order (nt3, 1, 2 - nt3): units 0..2 = tile A x them, 3 and 4 = tile B x the first two
+    f16x8 wh[3], wl[3];
+    constexpr int NB = ITA_UP_NB;                        // blend groups in flight
+    f32x4 v[NB][4];
+    auto ntq = [&](int q) { return q == 1 ? 1 : (q == 0 ? nt3 : 2 - nt3); };
+    auto ldwh = [&](int j) {
 #pragma unroll
-      for (int nt = 0; nt < 3; ++nt) c[m][nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+      for (int q = 0; q < 3; ++q) wh[q] = *(const f16x8*)(wb + ((j * 3 + ntq(q)) * 64 + lane) * 16);
+    };
+    auto ldwl = [&](int j) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f16x8 wh[3], wl[3];
+      for (int q = 0; q < 3; ++q) wl[q] = *(const f16x8*)(wb + L::WPL + ((j * 3 + ntq(q)) * 64 + lane) * 16);
+    };
+    auto ldv = [&](int g) {
+      v[g % NB][0] = *(const f32x4*)(p00 + 4 * g); v[g % NB][1] = *(const f32x4*)(p01 + 4 * g);
+      v[g % NB][2] = *(const f32x4*)(p10 + 4 * g); v[g % NB][3] = *(const f32x4*)(p11 + 4 * g);
+    };
+    if (DO_G) { ldwl(0); ldwh(0); }
+    if (DO_B) {
 #pragma unroll
-      for (int nt = 0; nt < 3; ++nt) {
-        wh[nt] = *(const f16x8*)(wb + ((j * 3 + nt) * 64 + lane) * 16);
-        wl[nt] = *(const f16x8*)(wb + L::WPL + ((j * 3 + nt) * 64 + lane) * 16);
+      for (int g = 0; g < NB; ++g) ldv(g);
+    }
+    // twelve micro-steps: five MFMAs (one split-precision product of the five units) | the FMAs of one blend group | reads
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const int j = i / 3, pr = i % 3;                   // products in the order lo.hi, hi.lo, hi.hi: wl is free after the first
+      if (DO_G) {
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          const int m = u < 3 ? 0 : 1, q = u < 3 ? u : u - 3;
+          c[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pr == 0 ? wl[q] : wh[q], pr == 1 ? xl[m][j] : xh[m][j], c[u], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (pr == 0 && j < 3) ldwl(j + 1);
+        if (pr == 2 && j < 3) ldwh(j + 1);
+        __builtin_amdgcn_sched_barrier(0);
       }
+      if (DO_B) {
+        // (explicit fma: the library is built with -ffp-contract=off)
+#if ITA_UP_PKFMA
+        acc[i] = __builtin_elementwise_fma(q00, v[i % NB][0], acc[i]);
+        acc[i] = __builtin_elementwise_fma(q01, v[i % NB][1], acc[i]);
+        acc[i] = __builtin_elementwise_fma(q10, v[i % NB][2], acc[i]);
+        acc[i] = __builtin_elementwise_fma(q11, v[i % NB][3], acc[i]);
+#else
+        // scalar v_fmac_f32, not v_pk_fma_f32: beside MFMAs a packed f32 FMA costs ~20 cycles more than the two scalar ones
+        // (MI355X guide, 'price of one filler beside MFMAs'); hipcc packs whatever it sees, hence the asm
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        if (m < nmt) {
+        for (int nb = 0; nb < 4; ++nb) {
+          const float kq = nb == 0 ? q00[0] : nb == 1 ? q01[0] : nb == 2 ? q10[0] : q11[0];
 #pragma unroll
-          for (int nt = 0; nt < 3; ++nt) {
-            c[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], xl[m][j], c[m][nt], 0, 0, 0);
-            c[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], xh[m][j], c[m][nt], 0, 0, 0);
-            c[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], xh[m][j], c[m][nt], 0, 0, 0);
+          for (int e = 0; e < 4; ++e) {
+            float r = acc[i][e];
+            asm("v_fmac_f32 %0, %1, %2" : "+v"(r) : "v"(kq), "v"(v[i % NB][nb][e]));
+            acc[i][e] = r;
           }
         }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + NB < 12) ldv(i + NB);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // C layout: lane = (token column lane & 15, output channels 4 (lane >> 4) .. + 3 of N tile nt)
+    if (DO_G) {
+      // C layout: lane = (token column lane & 15, output channels 4 (lane >> 4) .. + 3 of the N tile)
+      const int rowA = (16 * wave + (lane & 15)) * L::YLD + 4 * (lane >> 4);
+      const int rowB = (16 * (8 + (wave & 3)) + (lane & 15)) * L::YLD + 4 * (lane >> 4);
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-      if (m < nmt) {
-#pragma unroll
-        for (int nt = 0; nt < 3; ++nt)
-          *(f32x4*)(ys + (16 * (wave + 8 * m) + (lane & 15)) * L::YLD + 16 * nt + 4 * (lane >> 4)) = c[m][nt];
-      }
-  };
-  auto blend = [&](int t) {
-    const int dy = t / 3, dx = t - 3 * dy;
-    const float* ys = (const float*)(lds + L::Y + (t & 1) * L::YB);
-    const float ok = vy[dy] * vx[dx];                              // 0: the tap's position lies in the conv's zero padding
-    const float h1 = h1v[dy], h0 = 1.0f - h1, w1 = w1v[dx], w0 = 1.0f - w1;
-    const float k00 = ok * (h0 * w0), k01 = ok * (h0 * w1), k10 = ok * (h1 * w0), k11 = ok * (h1 * w1);
-    const f32x4 q00 = {k00, k00, k00, k00}, q01 = {k01, k01, k01, k01}, q10 = {k10, k10, k10, k10}, q11 = {k11, k11, k11, k11};
-    const float* p00 = ys + rowo[dy] + colo[dx];
-    const float* p01 = p00 + xpo[dx];
-    const float* p10 = p00 + ypo[dy];
-    const float* p11 = p10 + xpo[dx];
-#pragma unroll
-    for (int g = 0; g < 12; ++g) {
-      const f32x4 v00 = *(const f32x4*)(p00 + 4 * g), v01 = *(const f32x4*)(p01 + 4 * g);
-      const f32x4 v10 = *(const f32x4*)(p10 + 4 * g), v11 = *(const f32x4*)(p11 + 4 * g);
-      // (explicit fma: the library is built with -ffp-contract=off)
-      acc[g] = __builtin_elementwise_fma(q00, v00, acc[g]);
-      acc[g] = __builtin_elementwise_fma(q01, v01, acc[g]);
-      acc[g] = __builtin_elementwise_fma(q10, v10, acc[g]);
-      acc[g] = __builtin_elementwise_fma(q11, v11, acc[g]);
+      for (int q = 0; q < 3; ++q) *(f32x4*)(ysw + rowA + 16 * ntq(q)) = c[q];
+      *(f32x4*)(ysw + rowB + 16 * nt3) = c[3];
+      *(f32x4*)(ysw + rowB + 16) = c[4];              // (both waves of a SIMD store this unit: the same bits from the same instruction sequence; a branch here would let the compiler sink the blend's FMAs behind it)
     }
   };
+  using std::true_type; using std::false_type;
 
   ITA_UP_ST(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of W[0] have landed
+  __syncthreads();
+  stage_w(1);
+  stage_w2(a.s_lo, L::WL2);                            // phase 2's weights: lo plane now, hi plane once weight buffer 1 is free
+  tap(true_type{}, false_type{}, 0);
 #pragma unroll 1
-  for (int t = 0; t < 9; ++t) {
+  for (int t = 1; t < 9; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of W[t] have landed
     __syncthreads();                                   // W[t] complete; GEMM(t-1) done by every wave: Y[(t-1)&1] complete, W[(t+1)&1] free; blend(t-2) done: Y[t&1] free
     if (t + 1 < 9) stage_w(t + 1);
-    if (t == 0) stage_w2(a.s_lo, L::WL2);                // phase 2's weights: lo plane now, hi plane once weight buffer 1 is free
     if (t == 8) stage_w2(a.s_hi, L::WH2);
 #ifndef ITA_UP_ABLATE
-#define ITA_UP_ABLATE 0
+    tap(true_type{}, true_type{}, t);
+#elif ITA_UP_ABLATE == 1
+    tap(false_type{}, true_type{}, t);                 // timing experiments only: wrong results
+#elif ITA_UP_ABLATE == 2
+    tap(true_type{}, false_type{}, t);
+#elif ITA_UP_ABLATE == 4
+    tap(true_type{}, true_type{}, t);
+#else
+    (void)t;
 #endif
-    if (!(ITA_UP_ABLATE & 1)) gemm(t);
-    if (!(ITA_UP_ABLATE & 2)) { if (t > 0) blend(t - 1); }
   }
   __syncthreads();
-  if (!(ITA_UP_ABLATE & 2)) blend(8);
+  tap(false_type{}, true_type{}, 9);
   ITA_UP_ST(2);
 
   // ================= phase 2: the E/4 pixel-shuffle channels -- PixelShuffle(2): out[c][2h+i][2w+j] = in[4c+2i+j][h][w], a plain
@@ -970,8 +1026,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      if (m < nmt) {
-        const int slot = 16 * (wave + 8 * m) + (lane & 15);
+      if (m == 0 || heavy) {                                                          // (tile B is held by both waves of a SIMD)
+        const int slot = 16 * (m ? 8 + (wave & 3) : wave) + (lane & 15);
         const int r = slot / L::RW, c = slot - L::RW * r;
         const int th_ = ry0 + r, tw_ = rx0 + c;                                        // (clamped copies beyond the grid: skipped)
         const bool tok_ok = slot < L::RH * L::RW && th_ < a.TH && tw_ < a.TW;
@@ -1033,10 +1089,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __syncthreads();       // halo and weights consumed: the interpolated part moves into LDS as U[co][pixel] (row stride 516)
     ITA_UP_ST(8);
     float* U = (float*)lds;
+#if !defined(ITA_UP_ABLATE) || ITA_UP_ABLATE != 4
 #pragma unroll
     for (int g = 0; g < 12; ++g)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) U[(4 * g + i) * 516 + tid] = acc[g][i];   // (raw: a VALU temporary between the stores serialises them -- each multiply waited for the previous ds_write to have read its operand, 8 us for the 48)
+      for (int i = 0; i < 4; ++i) U[(4 * g + i) * 516 + tid] = acc[g][i];
+#else
+    if (acc[0][0] == 12345.678f) U[tid] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + acc[4][0] + acc[5][0] + acc[6][0] + acc[7][0] + acc[8][0] + acc[9][0] + acc[10][0] + acc[11][0];
+#endif   // (raw: a VALU temporary between the stores serialises them -- each multiply waited for the previous ds_write to have read its operand, 8 us for the 48)
     ITA_UP_ST(9);
     __syncthreads();
     ITA_UP_ST(7);
