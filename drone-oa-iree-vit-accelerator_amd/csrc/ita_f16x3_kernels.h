@@ -790,7 +790,7 @@ struct ItaTailUpLds {
 };
 
 #ifndef ITA_UP_NB
-#define ITA_UP_NB 3
+#define ITA_UP_NB 2
 #endif
 #ifndef ITA_UP_PKFMA
 #define ITA_UP_PKFMA 0
@@ -798,7 +798,7 @@ struct ItaTailUpLds {
 #ifdef ITA_UP_STAMP
 // diagnostic build only (tools/tail_up_stamps.py): s_memrealtime (100 MHz) of every wave at the phase boundaries (<= 2048 workgroups)
 __device__ unsigned long long ita_up_stamp_buf[2048 * 8 * 12];
-#define ITA_UP_ST(i) do { if (lane == 0) ita_up_stamp_buf[((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave) * 12 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define ITA_UP_ST(i) do { if (lane == 0) ita_up_stamp_buf[((size_t)tile * 8 + wave) * 12 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define ITA_UP_ST(i) do { } while (0)
 #endif
@@ -806,12 +806,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   using L = ItaTailUpLds;
   constexpr int E = 128;
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
+  int tid = threadIdx.x, lane = tid & 63;              // (not const: re-derived per tile, see the tile loop)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int OH = 2 * a.TH, OW = 2 * a.TW;
-  const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 16, b = blockIdx.z;
-  const float* xt = a.x + (size_t)b * a.TH * a.TW * E;
   const float sy = (float)(a.TH - 1) / (float)(OH - 1), sx = (float)(a.TW - 1) / (float)(OW - 1);
+  // persistent: workgroup w runs tiles w, w + gridDim.x, ... (tile = (frame, tile row, tile column), column fastest).  At 160 KB
+  // of LDS a CU holds one workgroup, so with one workgroup per tile every token fetch (an HBM round trip, 1.3 - 3.7 us) and every
+  // workgroup launch was exposed: now the next tile's tokens are requested during phase 2, when the fragment registers are free
+  const int tiles_x = OW / 32, tiles_y = OH / 16, ntiles = tiles_x * tiles_y * a.B;
+  int tx0, ty0, b, ry0, rx0;
+  const float* xt;
   // source row / column of a clamped output coordinate: the oracle's upsample_src_ac (bilinear x2, align_corners=True)
   auto src = [](int q, float s, int n, int& i0, int& ip, float& l1) {
     const float f = s * (float)q;
@@ -819,9 +823,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (i > n - 1) i = n - 1;
     i0 = i; ip = i < n - 1 ? 1 : 0; l1 = f - (float)i;
   };
-  int ry0, rx0, dummy_i; float dummy_f;
-  src(max(ty0 - 1, 0), sy, a.TH, ry0, dummy_i, dummy_f);
-  src(max(tx0 - 1, 0), sx, a.TW, rx0, dummy_i, dummy_f);
+  auto set_tile = [&](int tile) {
+    const int bx = tile % tiles_x, r_ = tile / tiles_x;
+    tx0 = bx * 32; ty0 = (r_ % tiles_y) * 16; b = r_ / tiles_y;
+    xt = a.x + (size_t)b * a.TH * a.TW * E;
+    int dummy_i; float dummy_f;
+    src(max(ty0 - 1, 0), sy, a.TH, ry0, dummy_i, dummy_f);
+    src(max(tx0 - 1, 0), sx, a.TW, rx0, dummy_i, dummy_f);
+  };
 
   // ---- weights of taps 0 and 1 on their way into LDS (LDS-DMA: 24 pieces of 1 KB per tap, three per wave)
   auto stage_w = [&](int tap) {
@@ -834,39 +843,59 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                        (__attribute__((address_space(3))) void*)(lds + L::W + buf * 2 * L::WPL + piece * 1024), 16, 0, 0);
     }
   };
-  ITA_UP_ST(0);
   auto stage_w2 = [&](const _Float16* g, int dst) {
     for (int wc = wave; wc < L::W2_PLANE / 1024; wc += 8)     // 27 pieces per plane
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (wc * 64 + lane) * 8),
                                        (__attribute__((address_space(3))) void*)(lds + dst + wc * 1024), 16, 0, 0);
   };
-  stage_w(0);
 
   // ---- this wave's token tiles as B fragments (column = token, k = the 8 channels 32 j + 8 (lane >> 4) .. + 7 of each k-step), f16 hi / lo.
   // 12 M tiles of 16 tokens x 3 N tiles = 36 units for 8 waves: wave w owns tile w (three units) and shares tile 8 + (w & 3)
   // with its SIMD partner w ^ 4 -- waves 0..3 take its N tiles 0 and 1, waves 4..7 N tile 2 (and compute N tile 1 once more
-  // so that all waves run the same straight-line code; that copy is not stored): 5 / 4 units instead of 6 / 3
+  // so that all waves run the same straight-line code): 5 / 4 units instead of 6 / 3
   const bool heavy = wave < 4;
   const int nt3 = heavy ? 0 : 2;
+  f32x4 raw[2][4][2];                                         // a tile's tokens as loaded (64 registers: those of xh / xl)
   f16x8 xh[2][4], xl[2][4];
+  auto request_tokens = [&]() {                               // (of the tile set_tile() has just selected)
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const int slot = min(16 * (m ? 8 + (wave & 3) : wave) + (lane & 15), L::RH * L::RW - 1);   // (slots 180..191: unused copies)
-    const int r = slot / L::RW, c = slot - L::RW * r;
-    const float* tp = xt + ((size_t)min(ry0 + r, a.TH - 1) * a.TW + min(rx0 + c, a.TW - 1)) * E + 8 * (lane >> 4);
+    for (int m = 0; m < 2; ++m) {
+      const int slot = min(16 * (m ? 8 + (wave & 3) : wave) + (lane & 15), L::RH * L::RW - 1);   // (slots 180..191: unused copies)
+      const int r = slot / L::RW, c = slot - L::RW * r;
+      const float* tp = xt + ((size_t)min(ry0 + r, a.TH - 1) * a.TW + min(rx0 + c, a.TW - 1)) * E + 8 * (lane >> 4);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const f32x4 v0 = *(const f32x4*)(tp + 32 * j), v1 = *(const f32x4*)(tp + 32 * j + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        _Float16 h, l;
-        // element 2 e <-> channel offset e, element 2 e + 1 <-> offset 4 + e (the weight image uses the same order): dword e of a
-        // fragment is then the channel pair (c, c + 1) of pixel-shuffle parity e -- phase 2 writes it to its halo as it is
-        split_f16(v0[e], h, l); xh[m][j][2 * e] = h; xl[m][j][2 * e] = l;
-        split_f16(v1[e], h, l); xh[m][j][2 * e + 1] = h; xl[m][j][2 * e + 1] = l;
-      }
+      for (int j = 0; j < 4; ++j) { raw[m][j][0] = *(const f32x4*)(tp + 32 * j); raw[m][j][1] = *(const f32x4*)(tp + 32 * j + 4); }
     }
-  }
+  };
+  auto split_tokens = [&]() {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          _Float16 h, l;
+          // element 2 e <-> channel offset e, element 2 e + 1 <-> offset 4 + e (the weight image uses the same order): dword e of a
+          // fragment is then the channel pair (c, c + 1) of pixel-shuffle parity e -- phase 2 writes it to its halo as it is
+          split_f16(raw[m][j][0][e], h, l); xh[m][j][2 * e] = h; xl[m][j][2 * e] = l;
+          split_f16(raw[m][j][1][e], h, l); xh[m][j][2 * e + 1] = h; xl[m][j][2 * e + 1] = l;
+        }
+  };
+  int tile = blockIdx.x;
+  set_tile(tile);
+  request_tokens();
+  stage_w2(a.s_lo, L::WL2);                            // phase 2's lo weight plane lies behind everything else in the LDS: staged once
+
+#pragma unroll 1
+  for (; tile < ntiles; tile += gridDim.x) {
+  // everything derived from the thread id is recomputed per tile: hoisted out of this loop (hipcc does) the ~40 lane-dependent
+  // addresses and offsets stay live through phase 1 and spill
+  asm volatile("" : "+v"(tid));
+  lane = tid & 63;
+  ITA_UP_ST(0);
+  __syncthreads();                                     // the previous tile's hand-over reads are done: the LDS is free
+  stage_w(0);
+  split_tokens();
 
   // ---- this thread's output pixel (its source rows / columns and weights are recomputed per tap: 30 instructions against 96
   // packed FMAs, and 24 registers fewer across the loop)
@@ -984,14 +1013,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of W[0] have landed
   __syncthreads();
   stage_w(1);
-  stage_w2(a.s_lo, L::WL2);                            // phase 2's weights: lo plane now, hi plane once weight buffer 1 is free
   tap(true_type{}, false_type{}, 0);
 #pragma unroll 1
   for (int t = 1; t < 9; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of W[t] have landed
     __syncthreads();                                   // W[t] complete; GEMM(t-1) done by every wave: Y[(t-1)&1] complete, W[(t+1)&1] free; blend(t-2) done: Y[t&1] free
     if (t + 1 < 9) stage_w(t + 1);
-    if (t == 8) stage_w2(a.s_hi, L::WH2);
+    if (t == 8) stage_w2(a.s_hi, L::WH2);            // phase 2's hi plane: into weight buffer 1, free from here on
 #ifndef ITA_UP_ABLATE
     tap(true_type{}, true_type{}, t);
 #elif ITA_UP_ABLATE == 1
@@ -1050,6 +1078,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     ITA_UP_ST(3);
+    const int tx0_c = tx0, ty0_c = ty0, b_c = b;
     f32x4 acc2[4][3];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -1086,6 +1115,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
     ITA_UP_ST(4);
+    // the next tile's tokens travel during the hand-over and the stores (the fragment registers are free since the halo was written;
+    // requested before the MFMA loop instead: +2 to 4 % on the launch).  Unconditional -- the last round fetches a tile again for
+    // nothing: a request under a condition would make the old contents of the 64 registers live through phase 1
+    set_tile(min(tile + (int)gridDim.x, ntiles - 1));
+    request_tokens();
     __syncthreads();       // halo and weights consumed: the interpolated part moves into LDS as U[co][pixel] (row stride 516)
     ITA_UP_ST(8);
     float* U = (float*)lds;
@@ -1112,7 +1146,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           f32x4 o;
 #pragma unroll
           for (int i = 0; i < 4; ++i) o[i] = (u[i] * a.inv_wscale + bco[nt]) + acc2[mt][nt][i] * a.inv_wscale;
-          *(f32x4*)(a.out + (((size_t)b * a.CO + co) * OH + ty0 + row) * OW + tx0 + col) = o;
+          *(f32x4*)(a.out + (((size_t)b_c * a.CO + co) * OH + ty0_c + row) * OW + tx0_c + col) = o;
         }
       }
     }
@@ -1122,4 +1156,5 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     ITA_UP_ST(6);
 #endif
   }
+  }   // tiles
 }

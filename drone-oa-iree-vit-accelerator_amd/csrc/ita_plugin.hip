@@ -1382,7 +1382,8 @@ int ita_fusion_tail_large(ita_handle h, const float* x, float* out, int batch, i
     };
     if (span_ok(tok_h, OH, 16, ItaTailUpLds::RH) && span_ok(tok_w, OW, 32, ItaTailUpLds::RW)) {
       ItaTailUpArgs u{x, h->tu_hi, h->tu_lo, h->ts_hi, h->ts_lo, h->tl_bias, h->tl_inv_scale, out, batch, tok_h, tok_w, h->tl_CO};
-      hipLaunchKernelGGL(ita_tail_up_kernel, dim3(OW / 32, OH / 16, batch), dim3(512), ItaTailUpLds::TOTAL, s, u);
+      const long ntiles = (long)(OW / 32) * (OH / 16) * batch;      // persistent: one workgroup per CU, tiles dealt round robin
+      hipLaunchKernelGGL(ita_tail_up_kernel, dim3((unsigned)(ntiles < h->num_cus ? ntiles : h->num_cus)), dim3(512), ItaTailUpLds::TOTAL, s, u);
       HIPCHK(hipGetLastError());
       return ITA_OK;
     }

@@ -36,6 +36,9 @@ for w in range(8):
         print(f"  {n:40s} mean {d.mean():7.2f}  p10 {np.percentile(d, 10):7.2f}  p90 {np.percentile(d, 90):7.2f} us")
 # how many workgroups does a CU run back to back, and with what gap?  (sort by start time; a CU's next workgroup starts when
 # the previous one ends: count starts inside 0.5 us after some end)
-starts, ends = np.sort(t[:, 0, 0]), np.sort(t[:, 0, 6])
-print(f"first 256 starts within {starts[255] - starts[0]:.2f} us; last end - last start {ends[-1] - starts[-1]:.2f} us")
+# persistent kernel: workgroup w runs tiles w, w + G, ...: gap between a tile's end and the next tile's start on the same workgroup
+G = 256
+if nwg > G:
+    gaps = t[G:, 0, 0] - t[:-G, 0, 6]
+    print(f"tile-to-tile gap on a workgroup (end of stores -> next tile's first stamp): mean {gaps.mean():.2f} us; tile period mean {np.mean(t[G:, 0, 0] - t[:-G, 0, 0]):.2f} us")
 eng.close()
