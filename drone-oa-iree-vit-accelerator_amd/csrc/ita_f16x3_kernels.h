@@ -948,6 +948,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int q = 0; q < 3; ++q) wl[q] = *(const f16x8*)(wb + L::WPL + ((j * 3 + ntq(q)) * 64 + lane) * 16);
     };
     auto ldv = [&](int g) {
+#if defined(ITA_UP_ABLATE) && ITA_UP_ABLATE == 5
+      if (g >= 4) return;                                // timing experiment: a third of the blend's LDS reads, all of its FMAs (wrong results)
+#endif
       v[g % NB][0] = *(const f32x4*)(p00 + 4 * g); v[g % NB][1] = *(const f32x4*)(p01 + 4 * g);
       v[g % NB][2] = *(const f32x4*)(p10 + 4 * g); v[g % NB][3] = *(const f32x4*)(p11 + 4 * g);
     };
@@ -1026,7 +1029,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     tap(false_type{}, true_type{}, t);                 // timing experiments only: wrong results
 #elif ITA_UP_ABLATE == 2
     tap(true_type{}, false_type{}, t);
-#elif ITA_UP_ABLATE == 4
+#elif ITA_UP_ABLATE == 4 || ITA_UP_ABLATE == 5
     tap(true_type{}, true_type{}, t);
 #else
     (void)t;
