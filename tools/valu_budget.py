@@ -3,13 +3,14 @@
 Compiles csrc/ita_plugin.hip to assembly, takes ita_stream_kernel<64, true, 1> from its frame-loop header to the end of the
 function (the loop body; inline-asm requantisation blocks are expanded in the assembly) and groups the opcodes.
 Counts are per WAVE and frame; a frame is 8 waves.  usage: python tools/valu_budget.py [extra hipcc flags]
-The single-rounding permission of a requantisation site is a run-time flag (both forms are in the code): count one form with
--DITA_FORCE_SITES=0 (exact everywhere) or -DITA_FORCE_SITES=63 (fast everywhere); -DITA_RQ_STYLE=2 is the round-2 form."""
+The single-rounding permission of the requantisation sites is a template argument: the default counts the FAST instantiation
+(all six sites of the layer proven at load time), --exact the other one; -DITA_RQ_STYLE=2 is the round-2 form."""
 import collections, os, re, subprocess, sys, tempfile
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, "drone-oa-iree-vit-accelerator_amd", "csrc", "ita_plugin.hip")
-KERNEL = "_Z17ita_stream_kernelILi64ELb1ELi1ELb0ELb0EEv13ItaStreamArgs"
+# <E = 64, FFN, TOK = 1, no stamps, f32 I/O, FAST>: the instantiation the bench blob runs; --exact counts the one with FAST = false
+KERNEL = "_Z17ita_stream_kernelILi64ELb1ELi1ELb0ELb0ELb%dEEv13ItaStreamArgs" % (0 if "--exact" in sys.argv else 1)
 CLASSES = [
     ("requantise: unbias + scale + round (v_pk_add/mul/fma_f32, v_pk_mov)", r"^v_pk_(add|mul|fma)_f32|^v_pk_mov"),
     ("requantise: float clamp (v_med3_f32)", r"^v_med3_f32"),
@@ -26,7 +27,7 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I",
-                               os.path.join(REPO, "include"), "--cuda-device-only", "-S", "-o", out, SRC] + sys.argv[1:],
+                               os.path.join(REPO, "include"), "--cuda-device-only", "-S", "-o", out, SRC] + [a for a in sys.argv[1:] if a != "--exact"],
                               stderr=subprocess.DEVNULL)
         lines = open(out).read().split("\n")
     beg = next(i for i, l in enumerate(lines) if l.startswith(KERNEL + ":"))
