@@ -603,8 +603,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   {
     int ol = lane;
     asm volatile("" : "+v"(ol));
+#ifndef ITA_PROLOGUE_ORDER
+#define ITA_PROLOGUE_ORDER 1     // 1: weights before pixels (round 3); 0: the round-2 order, pixels first
+#endif
     if constexpr (TOK != 0) {
-      tok_fetch(blockIdx.x, ol);
+      if (ITA_PROLOGUE_ORDER == 0) tok_fetch(blockIdx.x, ol);
     } else if constexpr (IO8) {
       const int8_t* xrow = a.xq + ((size_t)blockIdx.x * S + wave * 16 + (ol & 15)) * E + EC * (ol >> 4);
 #pragma unroll
@@ -632,26 +635,42 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       vw[j] = (i32x4){0, 0, 0, 0};
       if (p < NW) vw[j] = *(const i32x4*)(a.image + (size_t)p * 16);
     }
+    // Loads return in order.  The image (tables, weights) is L2-resident after the first workgroups, the first frame's pixels come
+    // from HBM: requested LAST, the 100 KB of the image reach LDS while the pixels are still on their way, and the tokenizer of the
+    // first frame is the only thing left between their arrival and the frame loop (the round-2 order -- pixels first, weights
+    // parked in registers until the tokenizer was done -- put the weights' LDS stores behind it)
+    if constexpr (TOK != 0) {
+      if (ITA_PROLOGUE_ORDER != 0) tok_fetch(blockIdx.x, ol);
+    }
     if (tid < 2 * P) colsum[tid] = ITA_ACC_BIAS;
 #pragma unroll
     for (int j = 0; j < NTJ; ++j) {
       const int p = tid + 512 * j;
       if (p < NT) *(i32x4*)(lds + (T0 + p) * 16) = vt[j];
     }
+    if constexpr (TOK != 0 && ITA_PROLOGUE_ORDER != 0) {
+#pragma unroll
+      for (int j = 0; j < NWJ; ++j) {
+        const int p = tid + 512 * j;
+        if (p < NW) *(i32x4*)(lds + p * 16) = vw[j];
+      }
+    }
     if constexpr (TOK != 0) {
       tok_fill(ol);
-      lds_barrier();   // tables in place (the weights are still in flight)
+      lds_barrier();   // tables (and, in the round-3 order, weights) in place
       tok_blend(ol);
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) tok_step(ct, ol);
       tok_finish(blockIdx.x, true, xr, ol);
     }
+    if constexpr (!(TOK != 0 && ITA_PROLOGUE_ORDER != 0)) {
 #pragma unroll
-    for (int j = 0; j < NWJ; ++j) {
-      const int p = tid + 512 * j;
-      if (p < NW) *(i32x4*)(lds + p * 16) = vw[j];
+      for (int j = 0; j < NWJ; ++j) {
+        const int p = tid + 512 * j;
+        if (p < NW) *(i32x4*)(lds + p * 16) = vw[j];
+      }
+      lds_barrier();   // weights, biases and column-sum bases in place
     }
-    lds_barrier();   // weights, biases and column-sum bases in place
     if constexpr (TOK == 0 && !IO8) tok_items_transpose<E>(xr);   // the first frame's rows were fetched as items (ld_tok_items)
   }
   if (STAMP && a.stamps && (tid & 255) == 0)
