@@ -105,17 +105,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// 73 KB of LDS and 128 registers: two workgroups per CU, four waves per SIMD -- this kernel is a stream of dependent MFMA -> requantise
+// -> softmax steps and at two waves per SIMD 30 % of the issue slots went unused.  K tiles: two-slot ring; V^T tiles (sweep 3 only): ONE
+// slot, staged at the start of a step and waited for behind that step's Q K^T and softmax; out_proj's fragments come straight from the
+// layer image in L2 (once per workgroup).
 struct ItaLongLds {
   static constexpr int KB = 128 * 192;                 // bytes per K or V^T image
-  static constexpr int K = 0, V = 2 * KB;              // two-slot rings
-  static constexpr int WO = 4 * KB;                    // int8 [12][128][16] out_proj fragment image
-  static constexpr int BO = WO + 128 * 192;            // int32 [128]: bo + ITA_ACC_BIAS
+  static constexpr int K = 0, V = 2 * KB;              // K: two-slot ring; V^T: one slot
+  static constexpr int BO = 3 * KB;                    // int32 [128]: bo + ITA_ACC_BIAS
   static constexpr int CS = BO + 128 * 4;              // int32 [192]: 128 * column sums of V over the whole sequence
   static constexpr int TOTAL = CS + 192 * 4;
+  static_assert(2 * TOTAL <= 160 * 1024, "two workgroups per CU");
 };
 
 template <bool FAST>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void ita_long_attn_kernel(const ItaLongArgs a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void ita_long_attn_kernel(const ItaLongArgs a) {
   constexpr int E = 128, S = 128, P = 192;
   using LI = ItaStreamLds<E, false, false>;   // offsets inside the layer's image
   using L = ItaLongLds;
@@ -139,7 +143,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   };
   stage(kimg, L::K);
   // out_proj fragments and bias from the layer's image; column sums of V over all key tiles of the frame
-  for (int p = tid; p < E * P / 16; p += 512) *(i32x4*)(lds + L::WO + p * 16) = *(const i32x4*)(a.image + LI::WO + (size_t)p * 16);
   if (tid < E / 4) *(i32x4*)(lds + L::BO + tid * 16) = *(const i32x4*)(a.image + LI::BIAS + (3 * P) * 4 + (size_t)tid * 16);
   if (tid < P) {
     int s = 0;
@@ -187,6 +190,41 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     epil(3, la[1]);
   };
+  // the same products, reduced to the running maximum of this lane's accumulators (all of them belong to query qi)
+  auto logits_max = [&](const char* kb, int& mx) {
+    struct KFr { i32x4 w[6]; } kfr[2];
+    i32x4 la[2][2];
+    auto ldk = [&](int p, KFr& f) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) f.w[t * 3 + ks] = *(const i32x4*)(kb + (((4 * ks + kq) * S + (2 * p + t) * 16 + qi) << 4));
+    };
+    auto mmk = [&](const KFr& f, i32x4 (&acc)[2]) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        acc[t] = (i32x4){ITA_ACC_BIAS, ITA_ACC_BIAS, ITA_ACC_BIAS, ITA_ACC_BIAS};
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.w[t * 3 + ks], qf[ks], acc[t], 0, 0, 0);
+      }
+    };
+    auto epil = [&](const i32x4 (&acc)[2]) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        mx = max(max(mx, acc[t][0]), acc[t][1]);           // (v_max3_i32)
+        mx = max(max(mx, acc[t][2]), acc[t][3]);
+      }
+    };
+    ldk(0, kfr[0]);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if (p + 1 < 4) ldk(p + 1, kfr[(p + 1) & 1]);
+      mmk(kfr[p & 1], la[p & 1]);
+      if (p > 0) epil(la[(p - 1) & 1]);
+      ITA_SCHED_BARRIER();
+    }
+    epil(la[1]);
+  };
   // one step of sweeps 1 and 2: steps are counted through the sweeps (step = sweep * nkt + kt), the K tile of a step sits in
   // ring slot step & 1 with its DMA waited for here; the next step's tile goes out after the barrier (the last step of a
   // sweep prefetches tile 0 for the next sweep)
@@ -197,16 +235,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     stage(kimg + (size_t)nx * L::KB, L::K + ((step + 1) & 1) * L::KB);
   };
 
-  // ---------------- sweep 1: row maximum
-  u16x2 m2 = {0, 0};
+  // ---------------- sweep 1: row maximum.  Requantisation is monotonic (m > 0; multiply, round and the biased 16-bit form all keep
+  // the order), so max_k rq(acc_k) = rq(max_k acc_k): the sweep keeps the maximum of the raw (biased) accumulators -- one v_max3_i32
+  // per two logits instead of the 2.25 to 2.75 instructions per logit of the requantisation -- and requantises ONE value per row
+  int mx = (int)0x80000000;
   for (int kt = 0; kt < nkt; ++kt) {
     next_tile(kt, kt);
-    u16x2 w[16];
-    logits(lds + L::K + (kt & 1) * L::KB, w);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) m2 = __builtin_elementwise_max(m2, w[j]);
+    logits_max(lds + L::K + (kt & 1) * L::KB, mx);
   }
-  int m = max1632_i(max((int)m2.x, (int)m2.y));
+  mx = max1632_i(mx);
+  int m;
+  {
+    const i32x4 am[2] = {(i32x4){mx, mx, mx, mx}, (i32x4){mx, mx, mx, mx}};
+    unsigned w4[4];
+    if constexpr (FAST) lg8_v3<ITA_RQ_FAST>(am, a.ml, w4);
+    else lg8_v3<ITA_RQ_EXACT>(am, a.ml, w4);
+    m = (int)(w4[0] & 0xffffu);
+  }
   m = min(max(m, 32768 - 128), 32768 + 127);
   const u16x2 mm = {(unsigned short)m, (unsigned short)m};
   const unsigned short capv = (unsigned short)min(m - (32768 - 128), 15);
@@ -234,16 +279,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int dg = 0; dg < 3; ++dg)
 #pragma unroll
     for (int t = 0; t < 4; ++t) va[dg][t] = *(const i32x4*)(lds + L::CS + ((4 * dg + t) * 16 + 4 * kq) * 4);
-  // (V tile 0 has to be on its way before the first step of this sweep waits for it)
-  stage(vimg, L::V + ((2 * nkt) & 1) * L::KB);
   for (int kt = 0; kt < nkt; ++kt) {
     const int step = 2 * nkt + kt;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nkt) {
-      stage(kimg + (size_t)(kt + 1) * L::KB, L::K + ((step + 1) & 1) * L::KB);
-      stage(vimg + (size_t)(kt + 1) * L::KB, L::V + ((step + 1) & 1) * L::KB);
-    }
+    __syncthreads();     // K tile kt landed; every wave is done with the previous step: the V^T slot and the other K slot are free
+    stage(vimg + (size_t)kt * L::KB, L::V);
+    if (kt + 1 < nkt) stage(kimg + (size_t)(kt + 1) * L::KB, L::K + ((step + 1) & 1) * L::KB);
     u16x2 w[16];
     logits(lds + L::K + (step & 1) * L::KB, w);
     i32x4 pf[2];
@@ -258,7 +299,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const unsigned p23 = __builtin_bit_cast(unsigned, (u16x2)(iv >> s1));
         pf[kb][t] = (int)(__builtin_amdgcn_perm(p23, p01, 0x06040200u) ^ 0x80808080u);
       }
-    const char* vb = lds + L::V + (step & 1) * L::KB;
+    // V^T tile kt (requested first: the three K pieces of the next step may still be on their way)
+    if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const char* vb = lds + L::V;
 #pragma unroll
     for (int st = 0; st < 6; ++st) {
       const int dg = st >> 1, kb = st & 1;
@@ -291,7 +336,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) {
       ItaF4 ob;
-      ld_frg_ks<E>(ob, lds + L::WO, 4 * eg, ks, qi, kq);
+      ld_frg_ks<E>(ob, a.image + LI::WO, 4 * eg, ks, qi, kq);      // (global: 48 KB per workgroup from L2, once)
       mm_ks(ob, cf[ks], oa);
     }
     *(i32x4*)(a.yq + (((size_t)b * a.S + (size_t)qt * 128 + token) * E) + 32 * kq + 16 * eg) = rq_group(oa, a.mo, FAST);
