@@ -641,7 +641,7 @@ def _long_inputs(seed, B, S, E=128):
     return np.clip(np.rint(x), -128, 127).astype(np.int8)
 
 
-@pytest.mark.parametrize("S,B", [(128, 3), (256, 2), (1024, 2), (2048, 1)])
+@pytest.mark.parametrize("S,B", [(128, 3), (256, 2), (384, 2), (1024, 2), (2048, 1)])
 def test_long_sequence_attention_equals_oracle(torch_cuda, oracle, S, B):
     """ita_mha_long_q8 (three sweeps over key tiles, logits never materialised) against the oracle's S x S form, bit for bit;
     at S = 128 also against ita_mha_q8, the single-tile stream kernel."""

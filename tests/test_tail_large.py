@@ -116,6 +116,32 @@ def test_gpu_tail_config5_size(oracle):
 
 
 @pytest.mark.gpu
+def test_gpu_tail_persistent_rounds(oracle):
+    """More tiles than CUs: 5 frames of config 5's map are 320 tiles for the 256 persistent workgroups of ita_tail_up_kernel, so
+    64 of them run a second tile (whose tokens they requested while finishing the first).  A frame's map must not depend on
+    the round or workgroup that produced it: every frame equals the same frame run alone, bit for bit; and frame 4 (second
+    round) is checked against the oracle at sampled points."""
+    import torch
+    E, th, tw, co, B = 128, 64, 128, 48, 5
+    c = synth.tail_large_case(9, E, th, tw, co, B)
+    eng = host.FusionTailLarge(c["conv_w"], c["conv_b"], device=0)
+    x = torch.from_numpy(c["x"]).cuda()
+    full = eng(x, th, tw)
+    for b in range(B):
+        alone = eng(x[b:b + 1].contiguous(), th, tw)
+        assert torch.equal(full[b], alone[0]), f"frame {b}"
+    got = full.cpu().numpy()
+    rs = np.random.RandomState(2)
+    n = 600
+    pts = np.stack([np.full(n, 4), rs.randint(0, co, n), rs.randint(0, 2 * th, n), rs.randint(0, 2 * tw, n)], 1)
+    pts[:4] = [[4, 0, 0, 0], [4, 47, 127, 255], [4, 11, 0, 255], [4, 30, 127, 0]]
+    want = oracle.tail_general_at(c["x"], th, tw, c["conv_w"], c["conv_b"], pts.astype(np.int32))
+    err = np.abs(got[pts[:, 0], pts[:, 1], pts[:, 2], pts[:, 3]] - want).max()
+    assert err <= 2e-5 * max(1.0, np.abs(want).max())
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_gpu_tail_large_rejects_bad_shapes():
     import torch
     c = synth.tail_large_case(0, 64, 4, 16, 9, 1)
