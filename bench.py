@@ -443,7 +443,7 @@ def main():
         img = torch.from_numpy(fr["img_u8"].astype(np.float32) / np.float32(255.0)).to(dev)
     dv, qt = torch.from_numpy(fr["desvel"]).to(dev), torch.from_numpy(fr["quat"]).to(dev)
     state = [(torch.zeros((3, B, 128), device=dev), torch.zeros((3, B, 128), device=dev)) for _ in range(2)]
-    vels = [torch.empty((B, 3), device=dev) for _ in range(2)]
+    vels = [torch.empty((B, 3), device=dev) for _ in range(3)]
     gather = itadist.VelocityGather(B, world, dev, total=total if strong else None)
     NG = 8                                        # time steps per graph replay
     sched = {"on": "graph", "off": "stream"}.get(a.hip_graph, a.schedule)
@@ -510,12 +510,31 @@ def main():
             if world > 1 and k == NG - 1:
                 gather.start(velring[half].reshape(NG * B, 3))
             return
-        vel = vels[i & 1]
-        if world > 1:
-            gather.ready()      # the all-gather of step i-2 read this velocity buffer
-        eng.forward(img, dv, qt, src, out=(vel, dst[0], dst[1]))
-        if world > 1:
-            gather.start(vel)
+        vel = vels[i % 3]
+        if world == 1:
+            eng.forward(img, dv, qt, src, out=(vel, dst[0], dst[1]))
+            return
+        # N > 1, one all-gather per step.  The collective of step i - 1 is enqueued BEHIND this step's encoder: issued right after
+        # fc(i - 1) its kernel becomes runnable in the same instant as the encoder, whose 256 persistent workgroups need every CU --
+        # when the collective wins that race the encoder's last workgroup starts 10-20 us late and the step is that much longer.
+        # Behind the encoder it runs beside the folded GEMM (128 KB of LDS and four waves per CU leave it room).  Same kernels and
+        # arithmetic as eng.forward (ita_vitlstm_encode / _fold / _back on one stream); three velocity buffers, because the
+        # all-gather that read buffer i % 3 is the one started two starts ago -- what gather.ready() waits for.
+        gather.ready()
+        eng.encode(img, i & 1)
+        if pending[0] is not None:
+            gather.start(pending[0])
+        eng.fold(B, i & 1, i % 3)
+        eng.back(dv, qt, src, (vel, dst[0], dst[1]), i % 3)
+        pending[0] = vel
+
+    pending = [None]      # the velocity buffer whose all-gather has not been started yet (N > 1, per-step gather)
+
+    def flush():
+        if pending[0] is not None:
+            gather.start(pending[0])
+            pending[0] = None
+        gather.finish()
 
     def fence():
         torch.cuda.synchronize()
@@ -525,7 +544,7 @@ def main():
 
     for i in range(W if graph is None else -(-W // NG) * NG):   # graph schedule: whole replays (>= W steps)
         step(i)
-    gather.finish()
+    flush()
     fence()
     # Clock settle: a short run (the driver's --steps 20 --warmup 5 is 2.7 ms of GPU work) is over before the GPU's power
     # management has settled under load (measured on MI355X boxes: the same kernels run 6 % slower in the first few ms after
@@ -533,7 +552,7 @@ def main():
     settle = max(0, a.settle_steps - W) // NG * NG
     for i in range(settle):
         step(i)
-    gather.finish()
+    flush()
     fence()
     # Untimed eager pass with HIP events around EVERY stage: the per-stage table and the dominant stage.
     # (Each event costs a ~5 us bubble in the stream, so this pass is slower than the timed one.)
@@ -563,7 +582,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(K):
         step(i)
-    gather.finish()
+    flush()
     fence()
     elapsed = time.perf_counter() - t0
     if live:
@@ -639,7 +658,9 @@ def main():
                        "gather_every": gather_every,
                        "gather": ("none (one GPU)" if world == 1 else
                                   f"asynchronous all-gather of the (frames, 3) velocities every {gather_every} step(s), "
-                                  f"double-buffered, backend {a.backend}"),
+                                  f"double-buffered, backend {a.backend}"
+                                  + (", each enqueued behind the next step's encoder launch (it runs beside the folded GEMM, not "
+                                     "in a race with the encoder's 256 persistent workgroups for CUs)" if gather_every == 1 and graph is None else "")),
                        "schedule": {"stream": "one stream",
                                     "graph": f"{NG} steps per HIP-graph replay on three streams: encoder(t+2) | folded GEMM(t+1) | LSTM + fc(t)",
                                     "pipelined": f"{NG} steps per ita_vitlstm_pipelined call: the library's two-stream loop, "
