@@ -798,7 +798,7 @@ struct ItaTailUpLds {
 #ifdef ITA_UP_STAMP
 // diagnostic build only (tools/tail_up_stamps.py): s_memrealtime (100 MHz) of every wave at the phase boundaries (<= 2048 workgroups)
 __device__ unsigned long long ita_up_stamp_buf[2048 * 8 * 12];
-#define ITA_UP_ST(i) do { if (lane == 0) ita_up_stamp_buf[((size_t)tile * 8 + wave) * 12 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define ITA_UP_ST(i) do { if (lane == 0 && tile < 2048) ita_up_stamp_buf[((size_t)tile * 8 + wave) * 12 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define ITA_UP_ST(i) do { } while (0)
 #endif

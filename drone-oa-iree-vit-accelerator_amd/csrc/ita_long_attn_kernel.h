@@ -6,7 +6,7 @@
 // depends on the row's GLOBAL maximum, and the probability floor((256 >> shift) * inv / 2^16) on the row's global sum, so
 // neither partial maxima nor partial sums of one sweep can be repaired afterwards ("Config 5").  Three
 // sweeps over the key tiles per query tile, each recomputing Q K^T on the matrix cores (the logits are never written out):
-//     sweep 1: row maximum                     (v_pk_max_u16 on the biased 16-bit logits)
+//     sweep 1: row maximum                     (of the RAW accumulators: requantisation is monotonic, one value per row is requantised)
 //     sweep 2: row sum of 256 >> (max - x)      (per key tile in 16-bit pairs, accumulated in 32 bits)
 //     sweep 3: probabilities -> A.V            (exactly ita_softmax_packed16's last step + the stream kernel's A.V)
 // Same arithmetic as the S = 128 stream kernel and the oracle (oracle/ita_oracle.c: ita_oracle_mha_q8 / _rows): int8 codes in,
@@ -15,9 +15,10 @@
 //   ita_long_proj_kernel : persistent, one 128-token tile at a time -- the stream kernel's projection phase (Q stays in
 //                          registers as MFMA B fragments, K and V^T are built as LDS images) and then the images go to
 //                          global memory verbatim: Q fragments, a 24 KB K image and a 24 KB V^T image + 192 column sums per tile
-//   ita_long_attn_kernel : one workgroup per (query tile, frame); wave w owns 16 queries; K (and in sweep 3 V^T) tiles arrive
-//                          by LDS-DMA into two-slot rings, one barrier per key tile; context requantised, out_proj from the
-//                          LDS-resident fragment image, codes stored 16 bytes per lane
+//   ita_long_attn_kernel : one workgroup per (query tile, frame), two workgroups per CU; wave w owns 16 queries; K tiles arrive
+//                          by LDS-DMA into a two-slot ring (one barrier per key tile), V^T tiles (sweep 3) into one slot (a second
+//                          barrier per step); context requantised, out_proj with its fragments from the layer image in L2,
+//                          codes stored 16 bytes per lane
 #pragma once
 #include "ita_stream_kernel.h"
 
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     round_pack16(f, pk);
     cf[dg] = (i32x4){(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
   }
-  __syncthreads();      // (WO / BO were written in the prologue: visible since the first barrier; keeps the waves together for the stores)
+  __syncthreads();      // (BO was written in the prologue: visible since the first barrier; keeps the waves together for the stores)
   const int token = wave * 16 + qi;
 #pragma unroll
   for (int eg = 0; eg < 2; ++eg) {
