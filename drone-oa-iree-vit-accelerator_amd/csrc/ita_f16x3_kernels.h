@@ -754,15 +754,17 @@ __global__ __launch_bounds__(64 * WAVES) void ita_tail_big_kernel(const ItaTailB
 // -- Y_t is a GEMM over the LOW-RESOLUTION tokens (a quarter of the pixels: 4x fewer MACs than the implicit GEMM on the
 // upsampled map, and no upsampled map, halo build or hi/lo split of 160 x 32768 values per frame), the interpolation an
 // exact f32 blend of four Y rows per tap.  Zero padding of the conv = taps whose position q falls outside the map are skipped.
-//   workgroup (512 threads) = one 16 x 32 output tile, all output channels; its source region is at most 10 x 18 tokens (host-checked)
-//   = 12 M tiles of 16 tokens: wave w owns tiles w and w + 8 (w < 4) -- a SIMD hosts waves w and w + 4, so the MFMA load per
-//   SIMD is equal -- with the tokens' f16 hi / lo fragments resident in registers for all nine taps;
+//   persistent workgroups (512 threads, one per CU: the kernel fills the 160 KB of LDS), tiles dealt round robin; a tile = 16 x 32
+//   output pixels, all output channels; its source region is at most 10 x 18 tokens (host-checked) = 12 M tiles of 16 tokens x 3 N
+//   tiles = 36 units, 5 / 4 per wave (details at the token load), the tokens' f16 hi / lo fragments resident in registers for all nine
+//   taps -- and requested for the NEXT tile as soon as phase 2 no longer needs them;
 //   per tap: Y_t = W_t . x^T on v_mfma_f32_16x16x32_f16 (three split-precision products, weights as the A operand so that a
 //   lane holds four consecutive output channels of one token: one 16-byte LDS store) -> Y slab [192 tokens][52] f32 in LDS;
-//   blend: thread = output pixel, 48 accumulators, four Y rows per tap (12 x ds_read_b128 each) with v_pk_fma_f32;
-//   one barrier per tap: GEMM(t) and blend(t - 1) of a wave run back to back, two Y slabs, two weight buffers (LDS-DMA).
-// The E/4 pixel-shuffle channels are no interpolation: phase 2 of the same workgroup runs them as the implicit GEMM of
-// ita_tail_big_kernel's chunk 0 (gathered halo in LDS), and the two parts are added in LDS and stored once, 16 bytes per lane.
+//   blend: thread = output pixel, 48 accumulators, four Y rows per tap (12 x ds_read_b128 each), scalar v_fmac_f32;
+//   one barrier per tap: GEMM(t) and blend(t - 1) of a wave as one software pipeline, two Y slabs, two weight buffers (LDS-DMA).
+// The E/4 pixel-shuffle channels are no interpolation: phase 2 of the same workgroup runs them as an implicit GEMM on the tile's
+// halo, written to LDS from the token fragments the waves hold (no second trip to memory), and the two parts are added in LDS and
+// stored once, 16 bytes per lane.  What bounds it: MFMA time + the blend's VALU issue, which add.
 struct ItaTailUpArgs {
   const float* x;                  // (B, TH*TW, 128)
   const _Float16 *w_hi, *w_lo;     // [9 taps][4 k-steps][3 N tiles][64 lanes][8]: A fragments (row = output channel), pre-scaled
