@@ -116,27 +116,29 @@ def test_gpu_tail_config5_size(oracle):
 
 
 @pytest.mark.gpu
-def test_gpu_tail_persistent_rounds(oracle):
-    """More tiles than CUs: 5 frames of config 5's map are 320 tiles for the 256 persistent workgroups of ita_tail_up_kernel, so
-    64 of them run a second tile (whose tokens they requested while finishing the first).  A frame's map must not depend on
-    the round or workgroup that produced it: every frame equals the same frame run alone, bit for bit; and frame 4 (second
-    round) is checked against the oracle at sampled points."""
+@pytest.mark.parametrize("B", [5, 32])
+def test_gpu_tail_persistent_rounds(oracle, B):
+    """More tiles than CUs: B frames of config 5's map are 64 B tiles for the 256 persistent workgroups of ita_tail_up_kernel
+    (B = 5: 64 of them run a second tile, whose tokens they requested while finishing the first; B = 32: the bench's own
+    launch, eight rounds).  A frame's map must not depend on the round or workgroup that produced it: frames equal the same
+    frame run alone, bit for bit; and points sampled over the later rounds are checked against the oracle."""
     import torch
-    E, th, tw, co, B = 128, 64, 128, 48, 5
+    E, th, tw, co = 128, 64, 128, 48
     c = synth.tail_large_case(9, E, th, tw, co, B)
     eng = host.FusionTailLarge(c["conv_w"], c["conv_b"], device=0)
     x = torch.from_numpy(c["x"]).cuda()
     full = eng(x, th, tw)
-    for b in range(B):
+    for b in sorted({0, 3, 4, B // 2, B - 1}):
         alone = eng(x[b:b + 1].contiguous(), th, tw)
         assert torch.equal(full[b], alone[0]), f"frame {b}"
-    got = full.cpu().numpy()
     rs = np.random.RandomState(2)
     n = 600
-    pts = np.stack([np.full(n, 4), rs.randint(0, co, n), rs.randint(0, 2 * th, n), rs.randint(0, 2 * tw, n)], 1)
-    pts[:4] = [[4, 0, 0, 0], [4, 47, 127, 255], [4, 11, 0, 255], [4, 30, 127, 0]]
+    pts = np.stack([rs.randint(4, B, n), rs.randint(0, co, n), rs.randint(0, 2 * th, n), rs.randint(0, 2 * tw, n)], 1)
+    pts[:4] = [[B - 1, 0, 0, 0], [B - 1, 47, 127, 255], [4, 11, 0, 255], [4, 30, 127, 0]]
+    got = full[torch.from_numpy(pts[:, 0]).cuda(), torch.from_numpy(pts[:, 1]).cuda(), torch.from_numpy(pts[:, 2]).cuda(),
+               torch.from_numpy(pts[:, 3]).cuda()].cpu().numpy()
     want = oracle.tail_general_at(c["x"], th, tw, c["conv_w"], c["conv_b"], pts.astype(np.int32))
-    err = np.abs(got[pts[:, 0], pts[:, 1], pts[:, 2], pts[:, 3]] - want).max()
+    err = np.abs(got - want).max()
     assert err <= 2e-5 * max(1.0, np.abs(want).max())
     eng.close()
 
