@@ -579,7 +579,8 @@ int launch_tokenizer(ita_context* c, const void* img, int dtype, float* tokens, 
   static const bool block_tok = getenv("ITA_TOK_BLOCK_KERNEL") != nullptr;
   if (c->tok_simg && !(block_tok && !u8)) {
     ItaTokStreamArgs ta{c->tok_simg + (u8 ? 0 : c->tok_simg_bytes), img, tokens, B};
-    const int g = B < c->num_cus ? B : c->num_cus;
+    static const int tok_wg = getenv("ITA_TOK_WG_PER_CU") ? atoi(getenv("ITA_TOK_WG_PER_CU")) : 2;   // 35 KB of LDS, <= 128 registers: two workgroups per CU
+    const int g = B < tok_wg * c->num_cus ? B : tok_wg * c->num_cus;
     if (c->hdr.E == 64) {
       if (u8) hipLaunchKernelGGL((ita_tok_stream_kernel<64, true>), dim3(g), dim3(512), (ItaTokStreamLds<64, true>::TOTAL), s, ta);
       else hipLaunchKernelGGL((ita_tok_stream_kernel<64, false>), dim3(g), dim3(512), (ItaTokStreamLds<64, false>::TOTAL), s, ta);

@@ -1046,7 +1046,7 @@ struct ItaTokStreamArgs {
   int B;
 };
 template <int E, bool U8>
-__global__ __launch_bounds__(512) void ita_tok_stream_kernel(const ItaTokStreamArgs a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void ita_tok_stream_kernel(const ItaTokStreamArgs a) {
   using L = ItaTokStreamLds<E, U8>;
   constexpr int S = 128, EC = E / 4, NCT = L::NCT;
   extern __shared__ __attribute__((aligned(16))) char lds[];
