@@ -617,7 +617,7 @@ class PipelinedSteps:
                 ev_fork.record(s_front)
                 s_fold.wait_event(ev_fork)
                 s_back.wait_event(ev_fork)
-                for i in range(n_steps):
+                def cap_encode(i):
                     if i >= 2:
                         s_front.wait_event(ev_planes[i - 2])       # encode(i) overwrites the planes fold(i-2) read
                     if i >= 3:
@@ -628,6 +628,8 @@ class PipelinedSteps:
                         s_front.wait_event(ev_back[i - 3])
                     engine.encode(self.img[i], i & 1, stream=s_front)
                     ev_enc[i].record(s_front)
+
+                def cap_fold_back(i):
                     s_fold.wait_event(ev_enc[i])
                     engine.fold(batch, i & 1, i % 3, stream=s_fold)
                     ev_front[i].record(s_fold)
@@ -635,6 +637,39 @@ class PipelinedSteps:
                     s_back.wait_event(ev_front[i])
                     engine.back(self.desvel[i], self.quat[i], (self.h, self.c), (self.vel[i], self.h, self.c), i % 3, stream=s_back)
                     ev_back[i].record(s_back)
+
+                # Node order of the capture (the dependencies are the same; ROCm 7.0's graph executor is sensitive to it -- tools/
+                # bench_small.py with ITA_GRAPH_ORDER).  Default: step by step, encode(i) fold(i) back(i).  "1": encode(i + 1) before
+                # fold(i) back(i).  A permutation of "EFB": level by level -- level s holds encode(s), fold(s - 1), back(s - 2), which
+                # do not depend on each other -- in that order inside a level.
+                order = os.environ.get("ITA_GRAPH_ORDER", "0")
+                if order == "1":
+                    cap_encode(0)
+                    for i in range(n_steps):
+                        if i + 1 < n_steps:
+                            cap_encode(i + 1)                       # (its waits -- fold(i - 1), back(i - 2) -- are recorded already)
+                        cap_fold_back(i)
+                elif sorted(order) == ["B", "E", "F"]:
+                    def cap_fold(i):
+                        s_fold.wait_event(ev_enc[i])
+                        engine.fold(batch, i & 1, i % 3, stream=s_fold)
+                        ev_front[i].record(s_fold)
+                        ev_planes[i].record(s_fold)
+
+                    def cap_back(i):
+                        s_back.wait_event(ev_front[i])
+                        engine.back(self.desvel[i], self.quat[i], (self.h, self.c), (self.vel[i], self.h, self.c), i % 3, stream=s_back)
+                        ev_back[i].record(s_back)
+
+                    for lvl in range(n_steps + 2):
+                        for ch in order:
+                            i = lvl - "EFB".index(ch)
+                            if 0 <= i < n_steps:
+                                {"E": cap_encode, "F": cap_fold, "B": cap_back}[ch](i)
+                else:
+                    for i in range(n_steps):
+                        cap_encode(i)
+                        cap_fold_back(i)
                 s_front.wait_stream(s_fold)                         # join
                 s_front.wait_stream(s_back)
             self.h.zero_()
